@@ -1,0 +1,353 @@
+/*
+ * badslam_hip.h -- C ABI of the MI355X-native BAD SLAM bundle-adjustment hot path.
+ *
+ * Every entry point here replaces one free function of the reference's operator
+ * boundary, applications/badslam/src/badslam/kernels.h (cited per function as
+ * "BS/kernels.h:<line>"), or one host loop of DirectBA
+ * (BS/direct_ba_alternating.cc, BS/direct_ba_pcg.cc).  Signatures use only plain
+ * pointers, sizes and the POD mirrors below, so the reference's C++ host code (or
+ * any FFI) can bind them without seeing HIP or torch types.
+ *
+ * Conventions (mirroring the reference):
+ *   - first argument after the context is the HIP stream (`void*` == hipStream_t),
+ *     BS/kernels.h passes cudaStream_t first everywhere;
+ *   - all image / surfel memory is owned by the caller and lives in device memory;
+ *   - small results written through host pointers are valid on return (the function
+ *     synchronises the stream, as BS/kernel_opt_pose.cc:96 does);
+ *   - return value: 0 on success, negative bslam_status on error.  The reference
+ *     aborts via CHECK()/LOG(FATAL) (BS/kernel_opt_pose.cc:58-61); we return the
+ *     code and keep the message in bslam_last_error().
+ */
+#ifndef BADSLAM_HIP_H_
+#define BADSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Constants (BS/kernels.cuh:38-93)                                           */
+/* ------------------------------------------------------------------------- */
+
+enum {
+  BSLAM_INVALID_DEPTH_BIT = 1 << 15,   /* kInvalidDepthBit   BS/kernels.cuh:38 */
+  BSLAM_UNKNOWN_DEPTH = 65535,         /* kUnknownDepth      BS/kernels.cuh:41 */
+  BSLAM_SURFEL_ACTIVE_FLAG = 1,        /* kSurfelActiveFlag  BS/kernels.cuh:44 */
+
+  /* surfel SoA rows (BS/kernels.cuh:69-93) */
+  BSLAM_SURFEL_X = 0,
+  BSLAM_SURFEL_Y = 1,
+  BSLAM_SURFEL_Z = 2,
+  BSLAM_SURFEL_NORMAL = 3,          /* u32: 3 x signed 10 bit */
+  BSLAM_SURFEL_RADIUS_SQUARED = 4,
+  BSLAM_SURFEL_COLOR = 5,           /* uchar4 rgb0 */
+  BSLAM_SURFEL_DESCRIPTOR1 = 6,
+  BSLAM_SURFEL_DESCRIPTOR2 = 7,
+  BSLAM_SURFEL_ACCUM0 = 8,          /* rows 8..16: scratch, no cross-call guarantees */
+  BSLAM_SURFEL_DATA_ATTRIBUTE_COUNT = 8,
+  BSLAM_SURFEL_ATTRIBUTE_COUNT = 17
+};
+
+/* Keyframe::Activation (BS/keyframe.h:54-67) */
+enum {
+  BSLAM_KF_ACTIVE = 0,
+  BSLAM_KF_COVISIBLE_ACTIVE = 1,
+  BSLAM_KF_INACTIVE = 2
+};
+
+typedef enum bslam_status {
+  BSLAM_OK = 0,
+  BSLAM_ERR_INVALID_ARGUMENT = -1,  /* a reference CHECK() would have fired */
+  BSLAM_ERR_HIP = -2,               /* a HIP runtime call failed */
+  BSLAM_ERR_NO_DEVICE = -3,         /* no gfx950 device visible */
+  BSLAM_ERR_OUT_OF_MEMORY = -4
+} bslam_status;
+
+/* ------------------------------------------------------------------------- */
+/* POD mirrors of the reference's kernel argument types                       */
+/* ------------------------------------------------------------------------- */
+
+/* = vis::CUDABuffer_<T> (libvis/src/libvis/cuda/cuda_buffer.cuh:115-118):
+ * element (y, x) lives at (T*)((char*)address + y * pitch) + x. */
+typedef struct bslam_buffer2d {
+  void* address;
+  int32_t height;
+  int32_t width;
+  size_t pitch; /* bytes */
+} bslam_buffer2d;
+
+/* = vis::CUDAMatrix3x4 (BS/cuda_matrix.cuh:140-142): three float4 rows. */
+typedef struct bslam_mat3x4 {
+  float m[12]; /* row-major: m[4*r + c] */
+} bslam_mat3x4;
+
+/* = vis::CUDAMatrix3x3 (BS/cuda_matrix.cuh:76-78): three float3 rows. */
+typedef struct bslam_mat3x3 {
+  float m[9]; /* row-major */
+} bslam_mat3x3;
+
+/* = vis::PinholeCamera4f parameters (libvis/src/libvis/camera.h:1740-1743):
+ * fx, fy, cx, cy in the pixel-CORNER convention, plus the image size. */
+typedef struct bslam_camera4f {
+  float fx, fy, cx, cy;
+  int32_t width, height;
+} bslam_camera4f;
+
+/* = vis::DepthParameters (BS/surfel_projection.cuh:129-149). */
+typedef struct bslam_depth_params {
+  bslam_buffer2d cfactor_buffer; /* float image, ceil(h/cell) x ceil(w/cell) */
+  float a;
+  float raw_to_float_depth;
+  float baseline_fx;
+  int32_t sparse_surfel_cell_size;
+} bslam_depth_params;
+
+/* The per-keyframe buffers DirectBA hands to the kernels
+ * (BS/keyframe.h:160-173,227-231).  `color` is the uchar4 buffer whose .w holds
+ * the luma (BS/cuda_image_processing.cu:173-174); MI355X has no texture unit, so
+ * the buffer replaces the reference's cudaTextureObject_t and the bilinear /
+ * clamp semantics of BS/keyframe.cc:67-73 are computed in the kernel. */
+typedef struct bslam_keyframe_view {
+  bslam_buffer2d depth;    /* u16 */
+  bslam_buffer2d normals;  /* u16 */
+  bslam_buffer2d radius;   /* u16 (IEEE half bits) */
+  bslam_buffer2d color;    /* uchar4 */
+  bslam_mat3x4 frame_T_global;
+  bslam_mat3x3 global_R_frame;
+  int32_t activation;      /* BSLAM_KF_* */
+  int32_t id;
+} bslam_keyframe_view;
+
+/* Pose of one keyframe as Sophus::SE3f stores it (unit quaternion xyzw +
+ * translation; libvis/third_party/sophus/sophus/se3.hpp). */
+typedef struct bslam_se3f {
+  float q[4]; /* x, y, z, w */
+  float t[3];
+} bslam_se3f;
+
+/* How the colour image is sampled where the reference uses tex2D() with
+ * cudaFilterModeLinear (BS/cost_function.cuh:140-156). */
+enum {
+  BSLAM_TEX_FIXED_POINT_1_8 = 0, /* NVIDIA texture unit semantics: 8 fractional weight bits */
+  BSLAM_TEX_EXACT_FLOAT = 1      /* exact fp32 bilinear weights */
+};
+
+/* Opaque context: owns the scratch the reference keeps in
+ * PoseEstimationHelperBuffers / IntrinsicsOptimizationHelperBuffers
+ * (BS/kernels.h:46-89) plus the per-launch partial-sum slabs. */
+typedef struct bslam_context bslam_context;
+
+/* ------------------------------------------------------------------------- */
+/* Library / context                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* Version of this ABI; bump on any signature change. */
+int bslam_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* bslam_last_error(void);
+
+/* Creates a context on HIP device `device`.  Fails with BSLAM_ERR_NO_DEVICE when
+ * no GPU is visible: there is no CPU fallback. */
+int bslam_create(int device, bslam_context** out_ctx);
+int bslam_destroy(bslam_context* ctx);
+
+/* Texture filtering mode (BSLAM_TEX_*), default BSLAM_TEX_FIXED_POINT_1_8. */
+int bslam_set_texture_mode(bslam_context* ctx, int mode);
+
+/* ------------------------------------------------------------------------- */
+/* Pose optimisation                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces AccumulatePoseEstimationCoeffsCUDA (BS/kernels.h:156-174,
+ * BS/kernel_opt_pose.cc:39-97): Gauss-Newton coefficients H (21, row-major upper
+ * triangle) and b (6) of one keyframe's pose over all surfels.  `residual_count`
+ * / `residual_sum` are filled when `debug` != 0 (quirk Q1 of the reference is
+ * kept: with descriptor residuals only the first one is counted,
+ * BS/kernel_opt_pose.cu:373-381).  H, b, residual_* are HOST pointers, valid on
+ * return.  Sums are combined in a fixed order (deterministic), unlike the
+ * reference's atomicAdd (BS/gauss_newton.cuh:71,89). */
+int bslam_accumulate_pose_estimation_coeffs(
+    bslam_context* ctx, void* stream,
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer,
+    const bslam_buffer2d* color_buffer,
+    const bslam_mat3x4* frame_T_global_estimate,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int debug, uint32_t* residual_count, float* residual_sum,
+    float* H, float* b);
+
+/* Replaces the keyframe loop around DirectBA::EstimateFramePose in
+ * BS/direct_ba_alternating.cc:543-577 (and EstimateFramePose itself, :42-283):
+ * all keyframes with activation != BSLAM_KF_INACTIVE advance in lock-step, one
+ * launch per Gauss-Newton iteration over (surfels x keyframes); the 6x6 solve
+ * (double LDLT, :206), the update global_T_frame * exp(-x) (:214) and the
+ * convergence test (BS/convergence_analysis.h:45-52) run on the device, so there
+ * is one host sync per iteration instead of one per keyframe and iteration.
+ * Surfels are frozen during this phase in the reference too, so per-keyframe
+ * results are those of the sequential loop up to summation order.
+ *   poses[K]            in/out, global_T_frame per keyframe
+ *   iterations_done[K]  out (may be NULL)
+ *   converged[K]        out (may be NULL)
+ * `allreduce` (may be NULL) is called once per iteration on the device buffer
+ * holding K x 32 floats of partial coefficients when surfels are sharded over
+ * several GPUs. */
+typedef int (*bslam_allreduce_fn)(void* user, void* device_buffer, size_t float_count, void* stream);
+
+int bslam_estimate_frame_poses_batched(
+    bslam_context* ctx, void* stream,
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int max_iterations,
+    bslam_se3f* poses, int32_t* iterations_done, int32_t* converged,
+    bslam_allreduce_fn allreduce, void* allreduce_user);
+
+/* One batched accumulation without the solve: H/b for all K keyframes at the
+ * given frame_T_global (kf.frame_T_global), written to HOST Hb[K][27] (21 H then
+ * 6 b) and counts[K] (number of depth-associated surfels).  Parity probe for the
+ * batched kernel and the unit the benchmark times. */
+int bslam_accumulate_pose_coeffs_batched(
+    bslam_context* ctx, void* stream,
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    float* Hb, uint32_t* counts);
+
+/* ------------------------------------------------------------------------- */
+/* Surfel activation / geometry                                               */
+/* ------------------------------------------------------------------------- */
+
+/* Replaces UpdateSurfelActivationCUDA (BS/kernels.h:262-269,
+ * BS/kernel_surfel_activation.cc:39-67): clears bit 0 of active_surfels[0..S) and
+ * sets it for every surfel associated with a pixel of an ACTIVE keyframe. */
+int bslam_update_surfel_activation(
+    bslam_context* ctx, void* stream,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels);
+
+/* Replaces UpdateSurfelNormalsCUDA (BS/kernels.h:225-232,
+ * BS/kernel_opt_geometry.cc:39-78). */
+int bslam_update_surfel_normals(
+    bslam_context* ctx, void* stream,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels);
+
+/* Replaces OptimizeGeometryIterationCUDA (BS/kernels.h:234-244,
+ * BS/kernel_opt_geometry.cc:80-201): normal update, then the position step
+ * (geometry-only) or the joint position+descriptor step.  Accumulators stay in
+ * registers across keyframes (keyframe order = list order, as the reference's
+ * serialised launches), scratch rows 8-16 are not touched. */
+int bslam_optimize_geometry_iteration(
+    bslam_context* ctx, void* stream,
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels);
+
+/* Per-surfel association probe (test / debugging aid; the reference has no such
+ * export, the tests need it to check the bit-exact parity target of
+ * SURVEY.md 8(a5)): for one keyframe writes out_pixel[i] = py * width + px of the
+ * associated pixel, or 0xffffffff when surfel i is not associated.  DEVICE ptr. */
+int bslam_debug_association(
+    bslam_context* ctx, void* stream,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    const bslam_keyframe_view* keyframe,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    uint32_t* out_pixel);
+
+/* ------------------------------------------------------------------------- */
+/* PCG (matrix-free Gauss-Newton step)                                        */
+/* ------------------------------------------------------------------------- */
+
+/* Unknown layout of BS/direct_ba_pcg.cc:270-306:
+ *   [6 per keyframe except the gauge keyframe | 1 or 3 per surfel |
+ *    4 + 1 + cfactor cells | 4 colour intrinsics] */
+typedef struct bslam_pcg_layout {
+  uint32_t unknown_count;
+  uint32_t surfel_unknown_start_index;
+  uint32_t depth_intrinsics_unknown_start_index; /* 0xffffffff if unused */
+  uint32_t a_unknown_index;                      /* 0xffffffff if unused */
+  uint32_t color_intrinsics_unknown_start_index; /* 0xffffffff if unused */
+  int32_t gauge_keyframe_id;                     /* pose of this keyframe is fixed */
+  int32_t optimize_poses, optimize_geometry;
+  int32_t optimize_depth_intrinsics, optimize_color_intrinsics;
+  int32_t use_depth_residuals, use_descriptor_residuals;
+} bslam_pcg_layout;
+
+/* The five PCG vectors and three scalars (device, float = PCGScalar,
+ * BS/kernels.cuh:62), each at least unknown_count long. */
+typedef struct bslam_pcg_vectors {
+  float* r;
+  float* M;
+  float* delta;
+  float* g;
+  float* p;
+  float* alpha_n; /* 1 float */
+  float* alpha_d; /* 1 float */
+  float* beta_n;  /* 1 float */
+} bslam_pcg_vectors;
+
+/* Replaces the K x PCGInitCUDA loop + memsets (BS/kernels.h:397-416,
+ * BS/direct_ba_pcg.cc:315-365): r0 = -J^T W F, M = diag(J^T W J). */
+int bslam_pcg_init(
+    bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_pcg_vectors* v);
+
+/* Replaces PCGInit2CUDA (BS/kernels.h:418-428). */
+int bslam_pcg_init2(bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
+                    float a, const bslam_pcg_vectors* v);
+
+/* Replaces the K x PCGStep1CUDA loop incl. its alpha_d / g memsets
+ * (BS/kernels.h:430-452, BS/direct_ba_pcg.cc:383-425).  Quirk Q7 (the epsilon
+ * term added once per keyframe) is reproduced. */
+int bslam_pcg_step1(
+    bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_pcg_vectors* v, int clear_g);
+
+/* Replaces PCGStep2CUDA (BS/kernels.h:454-465); *beta_n_host (HOST) valid on return. */
+int bslam_pcg_step2(bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
+                    const bslam_pcg_vectors* v, float* beta_n_host);
+
+/* Replaces PCGStep3CUDA (BS/kernels.h:467-473). */
+int bslam_pcg_step3(bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
+                    const bslam_pcg_vectors* v);
+
+/* Replaces UpdateSurfelsFromPCGDeltaCUDA (BS/kernels.h:483-489). */
+int bslam_update_surfels_from_pcg_delta(
+    bslam_context* ctx, void* stream, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int use_descriptor_residuals, uint32_t surfel_unknown_start_index, const float* pcg_delta);
+
+/* Replaces UpdateCFactorsFromPCGDeltaCUDA (BS/kernels.h:491-495). */
+int bslam_update_cfactors_from_pcg_delta(
+    bslam_context* ctx, void* stream, const bslam_buffer2d* cfactor_buffer,
+    uint32_t cfactor_unknown_start_index, const float* pcg_delta);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* BADSLAM_HIP_H_ */

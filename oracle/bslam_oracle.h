@@ -1,0 +1,157 @@
+/*
+ * bslam_oracle.h -- ORACLE (test infrastructure only).
+ *
+ * CPU restatement of the reference's bundle-adjustment hot path
+ * (/root/reference/applications/badslam/src/badslam, "BS/").  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / reported baseline.  The product (badslam_amd/) never
+ * links, imports or calls it.
+ *
+ * Pinning: the reference ships no golden vectors for this path (BS/test/ holds only
+ * GPU integration tests with closed-form answers).  The oracle is pinned by
+ * re-stating those known-answer scenarios (tests/test_oracle_known_answers.py):
+ * pose recovery < 1.1e-6 (BS/test/test_pose_optimization_geometric_residual.cc:168),
+ * < 8e-5 photometric (BS/test/test_pose_optimization_photometric_residual.cc:175),
+ * surfel depth < 1e-4 (BS/test/test_geometry_optimization_geometric_residual.cc:190-205).
+ * A reference build (oracle/_ref) is NOT possible in this image: the path's sources
+ * need <cuda_runtime.h>, <cub/cub.cuh>, Eigen and Sophus/Eigen headers that the
+ * image lacks, and stand-ins for missing headers are not allowed.
+ *
+ * All pointers are HOST pointers; the POD types are those of include/badslam_hip.h.
+ */
+#ifndef BSLAM_ORACLE_H_
+#define BSLAM_ORACLE_H_
+
+#include <stdint.h>
+
+#include "../include/badslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- SE3 helpers (Sophus::SE3f restated: libvis/third_party/sophus/sophus/{so3,se3}.hpp) */
+void bso_se3_identity(bslam_se3f* T);
+void bso_se3_exp(const float x[6], bslam_se3f* out);             /* se3.hpp:293-313, so3.hpp:282-318 */
+void bso_se3_log(const bslam_se3f* T, float out[6]);             /* se3.hpp:435-466, so3.hpp:421-466 */
+void bso_se3_mul(const bslam_se3f* a, const bslam_se3f* b, bslam_se3f* out);  /* se3.hpp operator*=, so3.hpp:215-232 */
+void bso_se3_inverse(const bslam_se3f* T, bslam_se3f* out);      /* se3.hpp inverse() */
+void bso_se3_matrix3x4(const bslam_se3f* T, bslam_mat3x4* out);  /* se3.hpp matrix3x4(), Eigen Quaternion::toRotationMatrix */
+void bso_se3_rotation(const bslam_se3f* T, bslam_mat3x3* out);
+/* Fills kf->frame_T_global and kf->global_R_frame from global_T_frame (BS/keyframe.h:160-173). */
+void bso_keyframe_set_pose(bslam_keyframe_view* kf, const bslam_se3f* global_T_frame);
+
+/* BS/convergence_analysis.h:45-52 */
+int bso_is_scale1_pose_estimation_converged(const float x[6]);
+
+/* H (21, upper triangle row-major) x = b in double via pivoted LDL^T, restating
+ * Eigen 3.3 LDLT (un-vendored dependency, "3.3.7 known to work", REF/README.md:79)
+ * as used at BS/direct_ba_alternating.cc:206.  n <= 6. */
+void bso_solve_ldlt_upper(int n, const float* H_upper, const float* b, float* x);
+
+/* ---- per-keyframe kernels ---- */
+
+/* out_pixel[i] = py*width+px or 0xffffffff (SurfelProjectsToAssociatedPixel,
+ * BS/surfel_projection_nvcc_only.cuh:302-332). */
+void bso_association(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+                     const bslam_keyframe_view* kf, uint32_t surfels_size, const bslam_buffer2d* surfels,
+                     uint32_t* out_pixel);
+
+/* AccumulatePoseEstimationCoeffsCUDA + kernel (BS/kernel_opt_pose.cc:39-97,
+ * BS/kernel_opt_pose.cu:251-383).  H[21], b[6] are fp32 sums in surfel-index order;
+ * H64/b64 (may be NULL) the same sums in double (per-term values still fp32).
+ * per_surfel (may be NULL): 8 floats per surfel
+ *   [depth raw residual, depth weight, desc r1, desc w1, desc r2, desc w2, flags, 0]
+ *   flags bit0 = depth-associated, bit1 = descriptor residuals valid. */
+void bso_accumulate_pose_estimation_coeffs(
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer, const bslam_buffer2d* color_buffer,
+    const bslam_mat3x4* frame_T_global, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int tex_mode, uint32_t* residual_count, float* residual_sum,
+    float* H, float* b, double* H64, double* b64, float* per_surfel);
+
+/* DirectBA::EstimateFramePose (BS/direct_ba_alternating.cc:42-283). */
+void bso_estimate_frame_pose(
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer, const bslam_buffer2d* color_buffer,
+    const bslam_se3f* global_T_frame_initial, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int tex_mode, int max_iterations, bslam_se3f* out_global_T_frame, int* iterations_done, int* converged);
+
+/* UpdateSurfelActivationCUDA (BS/kernel_surfel_activation.cc:39-67). */
+void bso_update_surfel_activation(
+    const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels);
+
+/* UpdateSurfelNormalsCUDA (BS/kernel_opt_geometry.cc:39-78). */
+void bso_update_surfel_normals(
+    const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels);
+
+/* OptimizeGeometryIterationCUDA (BS/kernel_opt_geometry.cc:80-201). */
+void bso_optimize_geometry_iteration(
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels,
+    int tex_mode);
+
+/* ---- PCG (BS/kernel_pcg.cu, host pointers in bslam_pcg_vectors) ---- */
+void bso_pcg_init(const bslam_pcg_layout* layout,
+                  const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+                  const bslam_depth_params* dp,
+                  int keyframe_count, const bslam_keyframe_view* keyframes,
+                  uint32_t surfels_size, const bslam_buffer2d* surfels,
+                  const bslam_pcg_vectors* v, int tex_mode);
+void bso_pcg_init2(const bslam_pcg_layout* layout, float a, const bslam_pcg_vectors* v);
+void bso_pcg_step1(const bslam_pcg_layout* layout,
+                   const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+                   const bslam_depth_params* dp,
+                   int keyframe_count, const bslam_keyframe_view* keyframes,
+                   uint32_t surfels_size, const bslam_buffer2d* surfels,
+                   const bslam_pcg_vectors* v, int clear_g, int tex_mode);
+void bso_pcg_step2(const bslam_pcg_layout* layout, const bslam_pcg_vectors* v, float* beta_n_host);
+void bso_pcg_step3(const bslam_pcg_layout* layout, const bslam_pcg_vectors* v);
+void bso_update_surfels_from_pcg_delta(uint32_t surfels_size, const bslam_buffer2d* surfels,
+                                       int use_descriptor_residuals, uint32_t surfel_unknown_start_index,
+                                       const float* pcg_delta);
+void bso_update_cfactors_from_pcg_delta(const bslam_buffer2d* cfactor_buffer,
+                                        uint32_t cfactor_unknown_start_index, const float* pcg_delta);
+
+/* ---- scene construction (restates the producers either side of the path so the
+ * reference's known-answer scenes can be rebuilt; "next" rows of SURVEY.md 8f) ---- */
+
+/* ComputeBrightnessCUDA (BS/cuda_image_processing.cu:165-194): rgb (3 bytes/pixel,
+ * tightly packed) -> uchar4 with .w = luma. */
+void bso_compute_brightness(int width, int height, const uint8_t* rgb, const bslam_buffer2d* out_color);
+
+/* ComputeNormalsCUDA (BS/cuda_depth_processing.cu:134-255) followed by
+ * ComputePointRadiiAndRemoveIsolatedPixelsCUDA (:286-357), as the Keyframe
+ * constructor chains them (BS/keyframe.cc:116-138): in_depth -> kf depth / normals /
+ * radius (all u16, caller-allocated).  Returns min/max metric depth of valid pixels
+ * in *min_depth / *max_depth (BS/cuda_depth_processing.cu:391-465). */
+void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+                          const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth,
+                          const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,
+                          float* min_depth, float* max_depth);
+
+/* DirectBA::CreateSurfelsForKeyframe with filter_new_surfels = false
+ * (BS/direct_ba.cc:340-405; BS/kernel_supporting_surfels.cu:45-97 without merge;
+ * BS/kernel_create_surfels.cu:41-161,357-385).  Cell ownership is decided in raster /
+ * surfel-index order (the reference's atomicCAS race is not reproducible).  Appends at
+ * *surfels_size and returns the number of surfels created. */
+uint32_t bso_create_surfels_for_keyframe(
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp, const bslam_keyframe_view* kf, const bslam_se3f* global_T_frame,
+    uint32_t* surfels_size, uint32_t max_surfels, const bslam_buffer2d* surfels, int tex_mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSLAM_ORACLE_H_ */

@@ -1,0 +1,374 @@
+/*
+ * bso_math.h -- ORACLE (test infrastructure, never shipped, never on the product path).
+ *
+ * Plain-C restatement of the device math of the reference's bundle-adjustment hot
+ * path.  Every function cites the reference file:line it follows; the arithmetic is
+ * fp32 in the reference's operand order, compiled with -ffp-contract=off so that no
+ * FMA is formed (the HIP kernels are built the same way, which is what makes the
+ * integer outputs -- associated pixel, activation mask -- comparable bit for bit).
+ *
+ * BS/ = /root/reference/applications/badslam/src/badslam/
+ *
+ * Known, documented deviations from what the CUDA build computes:
+ *   - the reference is compiled with -use_fast_math (approximate division / sqrtf /
+ *     expf); this restatement uses IEEE division, sqrtf and libm expf;
+ *   - tex2D() bilinear filtering is modelled in software (bso_tex_w below).
+ */
+#ifndef BSO_MATH_H_
+#define BSO_MATH_H_
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/badslam_hip.h"
+
+typedef struct { float x, y, z; } bso_f3;
+typedef struct { float x, y; } bso_f2;
+
+static inline bso_f3 bso_make3(float x, float y, float z) { bso_f3 r = {x, y, z}; return r; }
+
+/* ---- BS/cuda_util.cuh:52-107 ------------------------------------------------ */
+static inline float bso_sqlen(bso_f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }           /* :52 */
+static inline float bso_dot(bso_f3 a, bso_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   /* :57 */
+static inline bso_f3 bso_cross(bso_f3 a, bso_f3 b) {                                            /* :78 */
+  return bso_make3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
+}
+static inline float bso_norm(bso_f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }     /* :85 */
+static inline bso_f3 bso_add(bso_f3 a, bso_f3 b) { return bso_make3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline bso_f3 bso_sub(bso_f3 a, bso_f3 b) { return bso_make3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline bso_f3 bso_scale(float m, bso_f3 b) { return bso_make3(m * b.x, m * b.y, m * b.z); }
+
+/* ---- BS/cuda_matrix.cuh:98-137 ---------------------------------------------- */
+static inline bso_f3 bso_mul34(const bslam_mat3x4* T, bso_f3 p) {                               /* :98 */
+  const float* m = T->m;
+  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
+                   m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+                   m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+static inline int bso_mul34_if_z_positive(const bslam_mat3x4* T, bso_f3 p, bso_f3* out) {       /* :113 */
+  const float* m = T->m;
+  out->z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+  if (out->z <= 0.f) return 0;
+  out->x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+  out->y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+  return 1;
+}
+static inline bso_f3 bso_rotate34(const bslam_mat3x4* T, bso_f3 p) {                            /* :129 */
+  const float* m = T->m;
+  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z,
+                   m[4] * p.x + m[5] * p.y + m[6] * p.z,
+                   m[8] * p.x + m[9] * p.y + m[10] * p.z);
+}
+static inline bso_f3 bso_mul33(const bslam_mat3x3* R, bso_f3 p) {                               /* :64 */
+  const float* m = R->m;
+  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z,
+                   m[3] * p.x + m[4] * p.y + m[5] * p.z,
+                   m[6] * p.x + m[7] * p.y + m[8] * p.z);
+}
+
+/* ---- pitched buffers (libvis/src/libvis/cuda/cuda_buffer.cuh:61-83) ---------- */
+#define BSO_AT(type, buf, y, x) \
+  (*((type*)((char*)(buf)->address + (size_t)(y) * (buf)->pitch) + (x)))
+
+/* ---- camera helpers (BS/surfel_projection.h:42-124, BS/surfel_projection.cuh) */
+typedef struct { float fx_inv, fy_inv, cx_inv, cy_inv; } bso_unprojector;  /* PixelCenterUnprojector */
+typedef struct { float fx, fy, cx, cy; int width, height; } bso_depth_to_color;  /* DepthToColorPixelCorner */
+
+static inline bso_unprojector bso_make_unprojector(const bslam_camera4f* c) {   /* BS/surfel_projection.h:58-67 */
+  bso_unprojector u;
+  u.fx_inv = 1.0f / c->fx;
+  u.fy_inv = 1.0f / c->fy;
+  const float cx_pixel_center = c->cx - 0.5f;
+  const float cy_pixel_center = c->cy - 0.5f;
+  u.cx_inv = -cx_pixel_center * u.fx_inv;
+  u.cy_inv = -cy_pixel_center * u.fy_inv;
+  return u;
+}
+static inline float bso_unproj_nx(const bso_unprojector* u, float px) { return u->fx_inv * px + u->cx_inv; }  /* BS/surfel_projection.cuh:116 */
+static inline float bso_unproj_ny(const bso_unprojector* u, float py) { return u->fy_inv * py + u->cy_inv; }
+static inline bso_f3 bso_unproject(const bso_unprojector* u, int x, int y, float depth) {   /* BS/surfel_projection.cuh:110-114 */
+  return bso_make3(depth * (u->fx_inv * x + u->cx_inv), depth * (u->fy_inv * y + u->cy_inv), depth);
+}
+static inline bso_f2 bso_project(float fx, float fy, float cx, float cy, bso_f3 p) {        /* BS/surfel_projection.cuh:52-55 */
+  bso_f2 r;
+  r.x = fx * (p.x / p.z) + cx;
+  r.y = fy * (p.y / p.z) + cy;
+  return r;
+}
+static inline bso_depth_to_color bso_make_depth_to_color(const bslam_camera4f* depth, const bslam_camera4f* color) {
+  /* BS/surfel_projection.h:105-124 */
+  bso_depth_to_color r;
+  r.width = color->width;
+  r.height = color->height;
+  r.fx = color->fx / depth->fx;
+  r.cx = -1 * color->fx * depth->cx / depth->fx + color->cx;
+  r.fy = color->fy / depth->fy;
+  r.cy = -1 * color->fy * depth->cy / depth->fy + color->cy;
+  return r;
+}
+static inline int bso_depth_to_color_pxy(bso_f2 pxy, const bso_depth_to_color* d, bso_f2* out) {   /* BS/surfel_projection.cuh:196-207 */
+  out->x = d->fx * pxy.x + d->cx;
+  out->y = d->fy * pxy.y + d->cy;
+  return out->x >= 0 && out->y >= 0 && (int)(out->x) < d->width && (int)(out->y) < d->height;
+}
+
+/* ---- BS/util.cuh:46-53 ------------------------------------------------------- */
+static inline float bso_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
+  const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
+  return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
+}
+
+/* ---- BS/util.cuh:101-130 ----------------------------------------------------- */
+static inline int8_t bso_small_float_to_s8(float value) {                                    /* :102 */
+  return (int8_t)(value * ((1 << 7) - 1) + ((value > 0) ? 0.5f : -0.5f));
+}
+static inline float bso_s8_to_small_float(int8_t value) { return value * (1.0f / ((1 << 7) - 1)); }   /* :107 */
+static inline uint16_t bso_image_space_normal_to_u16(float x, float y) {                     /* :114 */
+  return (uint16_t)(((uint16_t)(uint8_t)bso_small_float_to_s8(x)) << 0) |
+         (uint16_t)(((uint16_t)(uint8_t)bso_small_float_to_s8(y)) << 8);
+}
+static inline bso_f3 bso_u16_to_image_space_normal(uint16_t value) {                         /* :120 */
+  bso_f3 r;
+  r.x = bso_s8_to_small_float((int8_t)(value & 0x00ff));
+  r.y = bso_s8_to_small_float((int8_t)((value & 0xff00) >> 8));
+  r.z = 1 - r.x * r.x - r.y * r.y;
+  r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
+  return r;
+}
+
+/* ---- BS/util_nvcc_only.cuh:52-115 -------------------------------------------- */
+static inline bso_f3 bso_surfel_position(const bslam_buffer2d* s, uint32_t i) {               /* :59 */
+  return bso_make3(BSO_AT(float, s, BSLAM_SURFEL_X, i), BSO_AT(float, s, BSLAM_SURFEL_Y, i), BSO_AT(float, s, BSLAM_SURFEL_Z, i));
+}
+static inline void bso_surfel_set_position(const bslam_buffer2d* s, uint32_t i, bso_f3 p) {   /* :52 */
+  BSO_AT(float, s, BSLAM_SURFEL_X, i) = p.x;
+  BSO_AT(float, s, BSLAM_SURFEL_Y, i) = p.y;
+  BSO_AT(float, s, BSLAM_SURFEL_Z, i) = p.z;
+}
+static inline uint32_t bso_small_float_to_s10(float value) {                                  /* :68 */
+  return 0x03ff & (uint16_t)(int16_t)(value * ((1 << 9) - 1) + ((value > 0) ? 0.5f : -0.5f));
+}
+static inline float bso_s10_to_small_float(uint32_t value) {                                  /* :74 */
+  uint16_t temp = (uint16_t)(((0x0200 & value) ? 0xfc00 : 0) | (0x03ff & value));
+  int16_t s;
+  memcpy(&s, &temp, 2);
+  return s * (1.0f / ((1 << 9) - 1));
+}
+static inline void bso_surfel_set_normal(const bslam_buffer2d* s, uint32_t i, bso_f3 n) {     /* :80 */
+  uint32_t v = (bso_small_float_to_s10(n.x) << 0) | (bso_small_float_to_s10(n.y) << 10) | (bso_small_float_to_s10(n.z) << 20);
+  memcpy(&BSO_AT(float, s, BSLAM_SURFEL_NORMAL, i), &v, 4);
+}
+static inline bso_f3 bso_surfel_normal(const bslam_buffer2d* s, uint32_t i) {                 /* :88 */
+  uint32_t value;
+  memcpy(&value, &BSO_AT(float, s, BSLAM_SURFEL_NORMAL, i), 4);
+  bso_f3 n = bso_make3(bso_s10_to_small_float(value >> 0), bso_s10_to_small_float(value >> 10), bso_s10_to_small_float(value >> 20));
+  float factor = 1.0f / bso_norm(n);
+  return bso_scale(factor, n);
+}
+
+/* ---- BS/robust_weighting.cuh:39-86 ------------------------------------------- */
+static inline float bso_tukey_residual(float r, float k) {
+  if (fabsf(r) < k) {
+    const float quot = r / k;
+    const float term = 1.f - quot * quot;
+    return (1 / 6.f) * k * k * (1 - term * term * term);
+  } else {
+    return (1 / 6.f) * k * k;
+  }
+}
+static inline float bso_tukey_weight(float r, float k) {
+  if (fabsf(r) < k) {
+    const float quot = r / k;
+    const float term = 1.f - quot * quot;
+    return term * term;
+  } else {
+    return 0.f;
+  }
+}
+static inline float bso_huber_residual(float r, float k) {
+  const float a = fabsf(r);
+  if (a < k) return 0.5f * r * r;
+  return k * (a - 0.5f * k);
+}
+static inline float bso_huber_weight(float r, float k) {
+  const float a = fabsf(r);
+  return (a < k) ? 1.f : (k / a);
+}
+
+/* ---- BS/cost_function.cuh:44-103 (depth residual) ----------------------------- */
+#define BSO_DEPTH_RESIDUAL_WEIGHT 1.f          /* :44 */
+#define BSO_DEPTH_TUKEY 10.f                   /* :48 */
+#define BSO_DEPTH_UNCERTAINTY_FACTOR 0.1f      /* :52 */
+#define BSO_COS_NORMAL_COMPAT 0.76604f         /* BS/kernels.cuh:58 */
+
+static inline float bso_depth_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {      /* :81-83 */
+  return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
+}
+static inline float bso_depth_inv_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {  /* :86-88 */
+  return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
+}
+static inline float bso_depth_weight(float r) { return BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_weight(r, 1.f * BSO_DEPTH_TUKEY); }           /* :91-93 */
+static inline float bso_weighted_depth_residual(float r) { return BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_residual(r, 1.f * BSO_DEPTH_TUKEY); }  /* :96-98 */
+
+/* ---- BS/cost_function.cuh:105-181 (descriptor residual) ------------------------ */
+#define BSO_DESC_RESIDUAL_WEIGHT 1e-2f         /* :105 */
+#define BSO_DESC_HUBER 10.f                    /* :109 */
+static inline float bso_desc_weight(float r) { return 1.f * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_weight(r, BSO_DESC_HUBER); }            /* :177-179 */
+static inline float bso_weighted_desc_residual(float r) { return 1.f * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_residual(r, BSO_DESC_HUBER); }  /* :183-185 */
+
+/* ---- software model of the colour texture (BS/keyframe.cc:67-73) --------------
+ * pitch2D uchar4, clamp addressing, cudaFilterModeLinear, cudaReadModeNormalizedFloat,
+ * unnormalised coordinates; only the .w channel (luma) is ever read on this path.
+ * Linear filtering per the CUDA programming guide (texture fetching appendix):
+ *   xB = x - 0.5, i = floor(xB), alpha = frac(xB) (9-bit fixed point, 8 fractional bits)
+ *   tex = (1-a)(1-b) T[i,j] + a(1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1].
+ * mode BSLAM_TEX_FIXED_POINT_1_8 rounds alpha/beta to multiples of 1/256,
+ * mode BSLAM_TEX_EXACT_FLOAT keeps the fp32 fractions.  The exact rounding inside
+ * NVIDIA's texture unit is not published: PARITY UNPINNED for this one function. */
+static inline float bso_texel_w(const bslam_buffer2d* color, int ix, int iy) {
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix > color->width - 1) ix = color->width - 1;
+  if (iy > color->height - 1) iy = color->height - 1;
+  const uint8_t* px = (const uint8_t*)color->address + (size_t)iy * color->pitch + 4 * (size_t)ix;
+  return px[3] * (1.0f / 255.0f);
+}
+static inline float bso_tex_w(const bslam_buffer2d* color, float x, float y, int mode) {
+  const float xb = x - 0.5f;
+  const float yb = y - 0.5f;
+  const float fx = floorf(xb);
+  const float fy = floorf(yb);
+  float a = xb - fx;
+  float b = yb - fy;
+  if (mode == BSLAM_TEX_FIXED_POINT_1_8) {
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  }
+  /* clamp in float first so that huge coordinates cannot overflow the int conversion */
+  const float fxc = fminf(fmaxf(fx, -2.0f), (float)color->width);
+  const float fyc = fminf(fmaxf(fy, -2.0f), (float)color->height);
+  const int i = (int)fxc;
+  const int j = (int)fyc;
+  const float t00 = bso_texel_w(color, i, j);
+  const float t10 = bso_texel_w(color, i + 1, j);
+  const float t01 = bso_texel_w(color, i, j + 1);
+  const float t11 = bso_texel_w(color, i + 1, j + 1);
+  const float w00 = (1.0f - a) * (1.0f - b);
+  const float w10 = a * (1.0f - b);
+  const float w01 = (1.0f - a) * b;
+  const float w11 = a * b;
+  return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+}
+
+/* BS/cost_function.cuh:115-136 */
+static inline void bso_tangent_projections(bso_f3 gp, bso_f3 gn, float radius_squared, const bslam_mat3x4* frame_T_global,
+                                           float cfx, float cfy, float ccx, float ccy, bso_f2* t1_pxy, bso_f2* t2_pxy) {
+  const float kTangentScaling = 2.0f;
+  bso_f3 t1 = bso_cross(gn, (fabsf(gn.x) > 0.9f) ? bso_make3(0, 1, 0) : bso_make3(1, 0, 0));
+  t1 = bso_scale(sqrtf(radius_squared / fmaxf(1e-12f, bso_sqlen(t1))), bso_scale(kTangentScaling, t1));
+  *t1_pxy = bso_project(cfx, cfy, ccx, ccy, bso_mul34(frame_T_global, bso_add(gp, t1)));
+  bso_f3 t2 = bso_cross(gn, t1);
+  t2 = bso_scale(sqrtf(radius_squared / fmaxf(1e-12f, bso_sqlen(t2))), bso_scale(kTangentScaling, t2));
+  *t2_pxy = bso_project(cfx, cfy, ccx, ccy, bso_mul34(frame_T_global, bso_add(gp, t2)));
+}
+
+/* BS/cost_function.cuh:140-156 */
+static inline void bso_raw_descriptor_residual(const bslam_buffer2d* color, int tex_mode, bso_f2 pxy, bso_f2 t1, bso_f2 t2,
+                                               float d1, float d2, float* r1, float* r2) {
+  float intensity = bso_tex_w(color, pxy.x, pxy.y, tex_mode);
+  float t1_intensity = bso_tex_w(color, t1.x, t1.y, tex_mode);
+  float t2_intensity = bso_tex_w(color, t2.x, t2.y, tex_mode);
+  *r1 = (180.f * (t1_intensity - intensity)) - d1;
+  *r2 = (180.f * (t2_intensity - intensity)) - d2;
+}
+
+/* one of the three blocks of BS/cost_function.cuh:200-239: finite-difference image
+ * gradient at p from the four texel centres around it (tex2D at texel centres
+ * returns the texel itself, for both filter models). */
+static inline void bso_point_gradient(const bslam_buffer2d* color, bso_f2 p, float* dx, float* dy) {
+  int ix = (int)fmaxf(0.f, p.x - 0.5f);
+  int iy = (int)fmaxf(0.f, p.y - 0.5f);
+  float tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - ix));
+  float ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - iy));
+  float top_left = bso_texel_w(color, ix, iy);
+  float top_right = bso_texel_w(color, ix + 1, iy);
+  float bottom_left = bso_texel_w(color, ix, iy + 1);
+  float bottom_right = bso_texel_w(color, ix + 1, iy + 1);
+  *dx = (bottom_right - bottom_left) * ty + (top_right - top_left) * (1 - ty);
+  *dy = (bottom_right - top_right) * tx + (bottom_left - top_left) * (1 - tx);
+}
+
+/* BS/cost_function.cuh:191-254 (the three unused fetches :241-243 are dropped, quirk Q3) */
+static inline void bso_descriptor_jacobian_wrt_projected_position(const bslam_buffer2d* color, bso_f2 c, bso_f2 t1, bso_f2 t2,
+                                                                  float* gx1, float* gy1, float* gx2, float* gy2) {
+  float cdx, cdy, t1dx, t1dy, t2dx, t2dy;
+  bso_point_gradient(color, c, &cdx, &cdy);
+  bso_point_gradient(color, t1, &t1dx, &t1dy);
+  bso_point_gradient(color, t2, &t2dx, &t2dy);
+  *gx1 = 180.f * (t1dx - cdx);
+  *gy1 = 180.f * (t1dy - cdy);
+  *gx2 = 180.f * (t2dx - cdx);
+  *gy2 = 180.f * (t2dy - cdy);
+}
+
+/* ---- association (BS/surfel_projection_nvcc_only.cuh:49-127, 302-332) ---------- */
+typedef struct {
+  bso_f3 global_position;
+  bso_f3 local_position;
+  bso_f3 surfel_normal;        /* global */
+  float calibrated_depth;
+  int px, py;
+  bso_f2 pxy;
+} bso_projection;
+
+/* BS/util.cuh:67-99 */
+static inline int bso_project_surfel_to_image(int width, int height, const bslam_camera4f* cam, bso_f3 local, int* px, int* py, bso_f2* pxy) {
+  *pxy = bso_project(cam->fx, cam->fy, cam->cx, cam->cy, local);
+  *px = (int)pxy->x;
+  *py = (int)pxy->y;
+  if (pxy->x < 0 || pxy->y < 0 || *px >= width || *py >= height) return 0;
+  return 1;
+}
+
+/* IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127 */
+static inline int bso_is_associated_with_pixel(const bslam_buffer2d* surfels, uint32_t surfel_index, bso_f3 local_position,
+                                               const bslam_mat3x4* frame_T_global, const bslam_buffer2d* normals_buffer,
+                                               int px, int py, const bslam_depth_params* dp, uint16_t measured_depth,
+                                               float depth_tukey_parameter, const bso_unprojector* unproj,
+                                               bso_f3* surfel_normal, float* out_calibrated_depth) {
+  if (measured_depth & BSLAM_INVALID_DEPTH_BIT) return 0;
+  float calibrated_depth = bso_raw_to_calibrated_depth(
+      dp->a, BSO_AT(float, &dp->cfactor_buffer, py / dp->sparse_surfel_cell_size, px / dp->sparse_surfel_cell_size),
+      dp->raw_to_float_depth, measured_depth);
+  *out_calibrated_depth = calibrated_depth;
+  *surfel_normal = bso_surfel_normal(surfels, surfel_index);
+  bso_f3 local_normal_s = bso_rotate34(frame_T_global, *surfel_normal);
+  float stddev = bso_depth_stddev(bso_unproj_nx(unproj, px), bso_unproj_ny(unproj, py), calibrated_depth, local_normal_s, dp->baseline_fx);
+  const float thr = depth_tukey_parameter * stddev;
+  if (fabsf(local_position.z - calibrated_depth) > thr) return 0;
+  float surfel_distance = bso_norm(local_position);
+  float dot_angle = (1.0f / surfel_distance) * bso_dot(local_position, local_normal_s);
+  if (dot_angle > 0) return 0;
+  bso_f3 local_normal = bso_u16_to_image_space_normal(BSO_AT(uint16_t, normals_buffer, py, px));
+  float dot2 = bso_dot(local_normal_s, local_normal);
+  if (dot2 < BSO_COS_NORMAL_COMPAT) return 0;
+  return 1;
+}
+
+/* SurfelProjectsToAssociatedPixel (all result variants) BS/surfel_projection_nvcc_only.cuh:302-360,416-511 */
+static inline int bso_surfel_projects_to_associated_pixel(uint32_t surfel_index, uint32_t surfels_size, const bslam_buffer2d* surfels,
+                                                          const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer,
+                                                          const bslam_depth_params* dp, const bslam_camera4f* depth_camera,
+                                                          const bso_unprojector* unproj, const bslam_mat3x4* frame_T_global,
+                                                          bso_projection* r) {
+  if (surfel_index >= surfels_size) return 0;
+  r->global_position = bso_surfel_position(surfels, surfel_index);
+  if (!bso_mul34_if_z_positive(frame_T_global, r->global_position, &r->local_position)) return 0;
+  if (!bso_project_surfel_to_image(depth_buffer->width, depth_buffer->height, depth_camera, r->local_position, &r->px, &r->py, &r->pxy)) return 0;
+  return bso_is_associated_with_pixel(surfels, surfel_index, r->local_position, frame_T_global, normals_buffer, r->px, r->py, dp,
+                                      BSO_AT(uint16_t, depth_buffer, r->py, r->px), BSO_DEPTH_TUKEY, unproj,
+                                      &r->surfel_normal, &r->calibrated_depth);
+}
+
+#endif /* BSO_MATH_H_ */

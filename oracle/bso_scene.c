@@ -1,0 +1,249 @@
+/*
+ * bso_scene.c -- ORACLE (test infrastructure only; see bslam_oracle.h).
+ *
+ * Restates the producers on either side of the hot path so that the reference's
+ * known-answer scenes (the .cc files under BS/test/) can be rebuilt on the CPU: keyframe
+ * preprocessing (brightness, normals, radii) and surfel creation.
+ * BS/ = /root/reference/applications/badslam/src/badslam/
+ */
+#include <math.h>
+#include <stdlib.h>
+
+#include "bslam_oracle.h"
+#include "bso_math.h"
+
+/* ComputeBrightnessKernel BS/cuda_image_processing.cu:165-176 */
+void bso_compute_brightness(int width, int height, const uint8_t* rgb, const bslam_buffer2d* out_color) {
+  for (int y = 0; y < height; ++y) {
+    for (int x = 0; x < width; ++x) {
+      const uint8_t* c = rgb + 3 * ((size_t)y * width + x);
+      uint8_t intensity = (uint8_t)((0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2]) + 0.5f);
+      uint8_t* o = (uint8_t*)out_color->address + (size_t)y * out_color->pitch + 4 * (size_t)x;
+      o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = intensity;
+    }
+  }
+}
+
+/* IEEE binary16 conversions (CUDA __float2half_rn / __half2float, used at
+ * BS/cuda_depth_processing.cu:355 and BS/kernel_create_surfels.cu:118). */
+static uint16_t float_to_half_rn(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t mant = x & 0x007fffffu;
+  int32_t exp = (int32_t)((x >> 23) & 0xff);
+  if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x0200u : 0));
+  int32_t e = exp - 127 + 15;
+  if (e >= 0x1f) return (uint16_t)(sign | 0x7c00u);
+  if (e <= 0) {
+    if (e < -10) return (uint16_t)sign;
+    mant |= 0x00800000u;
+    uint32_t shift = (uint32_t)(14 - e);
+    uint32_t half_mant = mant >> shift;
+    uint32_t rem = mant & ((1u << shift) - 1);
+    uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_mant & 1))) half_mant++;
+    return (uint16_t)(sign | half_mant);
+  }
+  uint32_t half = (uint32_t)(e << 10) | (mant >> 13);
+  uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) half++;
+  return (uint16_t)(sign | half);
+}
+
+static float half_to_float(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1f;
+  uint32_t mant = h & 0x3ffu;
+  uint32_t x;
+  if (exp == 0) {
+    if (mant == 0) {
+      x = sign;
+    } else {
+      int e = -1;
+      do { ++e; mant <<= 1; } while (!(mant & 0x400u));
+      mant &= 0x3ffu;
+      x = sign | ((uint32_t)(127 - 15 - e) << 23) | (mant << 13);
+    }
+  } else if (exp == 0x1f) {
+    x = sign | 0x7f800000u | (mant << 13);
+  } else {
+    x = sign | ((exp + 127 - 15) << 23) | (mant << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+                          const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth,
+                          const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,
+                          float* min_depth_out, float* max_depth_out) {
+  const int w = in_depth->width, h = in_depth->height;
+  bso_unprojector u = bso_make_unprojector(depth_camera);
+  const int cell = dp->sparse_surfel_cell_size;
+  /* stage 1: ComputeNormalsCUDAKernel BS/cuda_depth_processing.cu:134-255 -> tmp depth + normals */
+  uint16_t* tmp = (uint16_t*)malloc((size_t)w * h * sizeof(uint16_t));
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      uint16_t* od = &tmp[(size_t)y * w + x];
+      uint16_t* on = &BSO_AT(uint16_t, out_normals, y, x);
+      const int kBorder = 1;
+      if (x < kBorder || y < kBorder || x >= w - kBorder || y >= h - kBorder) {
+        *od = BSLAM_UNKNOWN_DEPTH; *on = bso_image_space_normal_to_u16(0, 0); continue;
+      }
+      uint16_t c = BSO_AT(uint16_t, in_depth, y, x);
+      if (c & BSLAM_INVALID_DEPTH_BIT) { *od = BSLAM_UNKNOWN_DEPTH; *on = bso_image_space_normal_to_u16(0, 0); continue; }
+      uint16_t rr = BSO_AT(uint16_t, in_depth, y, x + 1);
+      uint16_t ll = BSO_AT(uint16_t, in_depth, y, x - 1);
+      uint16_t bb = BSO_AT(uint16_t, in_depth, y + 1, x);
+      uint16_t tt = BSO_AT(uint16_t, in_depth, y - 1, x);
+      if ((rr & BSLAM_INVALID_DEPTH_BIT) || (ll & BSLAM_INVALID_DEPTH_BIT) || (bb & BSLAM_INVALID_DEPTH_BIT) || (tt & BSLAM_INVALID_DEPTH_BIT)) {
+        *od = BSLAM_UNKNOWN_DEPTH; *on = bso_image_space_normal_to_u16(0, 0); continue;
+      }
+#define CF(yy, xx) BSO_AT(float, &dp->cfactor_buffer, (yy) / cell, (xx) / cell)
+      float center_depth = bso_raw_to_calibrated_depth(dp->a, CF(y, x), dp->raw_to_float_depth, c);
+      float left_depth = bso_raw_to_calibrated_depth(dp->a, CF(y, x - 1), dp->raw_to_float_depth, ll);
+      float top_depth = bso_raw_to_calibrated_depth(dp->a, CF(y - 1, x), dp->raw_to_float_depth, tt);
+      float right_depth = bso_raw_to_calibrated_depth(dp->a, CF(y, x + 1), dp->raw_to_float_depth, rr);
+      float bottom_depth = bso_raw_to_calibrated_depth(dp->a, CF(y + 1, x), dp->raw_to_float_depth, bb);
+#undef CF
+      bso_f3 left_point = bso_unproject(&u, x - 1, y, left_depth);
+      bso_f3 top_point = bso_unproject(&u, x, y - 1, top_depth);
+      bso_f3 right_point = bso_unproject(&u, x + 1, y, right_depth);
+      bso_f3 bottom_point = bso_unproject(&u, x, y + 1, bottom_depth);
+      bso_f3 center_point = bso_unproject(&u, x, y, center_depth);
+      const float kRatioThresholdSquared = 2.f * 2.f;
+      float left_dist_squared = bso_sqlen(bso_sub(left_point, center_point));
+      float right_dist_squared = bso_sqlen(bso_sub(right_point, center_point));
+      float left_right_ratio = left_dist_squared / right_dist_squared;
+      bso_f3 left_to_right;
+      if (left_right_ratio < kRatioThresholdSquared && left_right_ratio > 1.f / kRatioThresholdSquared) left_to_right = bso_sub(right_point, left_point);
+      else if (left_dist_squared < right_dist_squared) left_to_right = bso_sub(center_point, left_point);
+      else left_to_right = bso_sub(right_point, center_point);
+      float bottom_dist_squared = bso_sqlen(bso_sub(bottom_point, center_point));
+      float top_dist_squared = bso_sqlen(bso_sub(top_point, center_point));
+      float bottom_top_ratio = bottom_dist_squared / top_dist_squared;
+      bso_f3 bottom_to_top;
+      if (bottom_top_ratio < kRatioThresholdSquared && bottom_top_ratio > 1.f / kRatioThresholdSquared) bottom_to_top = bso_sub(top_point, bottom_point);
+      else if (bottom_dist_squared < top_dist_squared) bottom_to_top = bso_sub(center_point, bottom_point);
+      else bottom_to_top = bso_sub(top_point, center_point);
+      bso_f3 normal = bso_cross(left_to_right, bottom_to_top);
+      float length = bso_norm(normal);
+      if (!(length > 1e-6f)) {
+        normal = bso_make3(0, 0, -1);
+      } else {
+        float inv_length = ((u.fy_inv < 0) ? -1.0f : 1.0f) / length;
+        normal.x *= inv_length;
+        normal.y *= inv_length;
+      }
+      *on = bso_image_space_normal_to_u16(normal.x, normal.y);
+      *od = c;
+    }
+  }
+  /* stage 2: ComputePointRadiiAndRemoveIsolatedPixelsCUDAKernel<4> BS/cuda_depth_processing.cu:286-357 */
+  float min_depth = INFINITY, max_depth = 0.f;
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      const uint16_t d16 = tmp[(size_t)y * w + x];
+      if (d16 & BSLAM_INVALID_DEPTH_BIT) {
+        BSO_AT(uint16_t, out_depth, y, x) = BSLAM_UNKNOWN_DEPTH;
+        BSO_AT(uint16_t, out_radius, y, x) = 0;   /* the reference leaves it unwritten */
+        continue;
+      }
+      /* min/max over the stage-1 depth (BS/keyframe.cc:140-147, BS/cuda_depth_processing.cu:391-465) */
+      float dm = dp->raw_to_float_depth * d16;
+      if (dm < min_depth) min_depth = dm;
+      if (dm > max_depth) max_depth = dm;
+      float depth = dp->raw_to_float_depth * d16;
+      bso_f3 local = bso_make3(depth * (u.fx_inv * x + u.cx_inv), depth * (u.fy_inv * y + u.cy_inv), depth);
+      int neighbor_count = 0;
+      float min_sq = INFINITY;
+      for (int dy = y - 1; dy < y + 2; ++dy) {
+        for (int dx = x - 1; dx < x + 2; ++dx) {
+          if ((dx != x && dy != y) || (dx == x && dy == y)) continue;
+          uint16_t dd = tmp[(size_t)dy * w + dx];   /* interior only: stage 1 invalidates the 1-pixel border */
+          if (dd & BSLAM_INVALID_DEPTH_BIT) continue;
+          ++neighbor_count;
+          float ddepth = dp->raw_to_float_depth * dd;
+          bso_f3 other = bso_make3(ddepth * (u.fx_inv * dx + u.cx_inv), ddepth * (u.fy_inv * dy + u.cy_inv), ddepth);
+          float dsq = bso_sqlen(bso_sub(other, local));
+          if (dsq < min_sq) min_sq = dsq;
+        }
+      }
+      int valid = neighbor_count >= 4;
+      BSO_AT(uint16_t, out_radius, y, x) = float_to_half_rn(valid ? min_sq : 0);
+      BSO_AT(uint16_t, out_depth, y, x) = valid ? d16 : BSLAM_UNKNOWN_DEPTH;
+    }
+  }
+  free(tmp);
+  if (min_depth_out) *min_depth_out = min_depth;
+  if (max_depth_out) *max_depth_out = max_depth;
+}
+
+uint32_t bso_create_surfels_for_keyframe(
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp, const bslam_keyframe_view* kf, const bslam_se3f* global_T_frame,
+    uint32_t* surfels_size, uint32_t max_surfels, const bslam_buffer2d* surfels, int tex_mode) {
+  const int w = kf->depth.width, h = kf->depth.height;
+  const int cell = dp->sparse_surfel_cell_size;
+  const int cw = (w - 1) / cell + 1, ch = (h - 1) / cell + 1;
+  bso_unprojector unproj = bso_make_unprojector(depth_camera);
+  bso_depth_to_color d2c = bso_make_depth_to_color(depth_camera, color_camera);
+  bslam_mat3x4 global_T_frame_m;
+  bso_se3_matrix3x4(global_T_frame, &global_T_frame_m);
+
+  /* DetermineSupportingSurfelsCUDAKernel<.., false> BS/kernel_supporting_surfels.cu:45-97:
+   * only "cell occupied or not" matters for creation. */
+  uint8_t* occupied = (uint8_t*)calloc((size_t)cw * ch, 1);
+  for (uint32_t i = 0; i < *surfels_size; ++i) {
+    bso_projection r;
+    if (bso_surfel_projects_to_associated_pixel(i, *surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r))
+      occupied[(size_t)(r.py / cell) * cw + (r.px / cell)] = 1;
+  }
+  /* CreateSurfelsForKeyframeCUDASerializingKernel BS/kernel_create_surfels.cu:41-72 (raster order wins the cell),
+   * inclusive scan (:427-460), CreationAppendKernel (:357-385) + CreateNewSurfel (:96-161). */
+  uint32_t created = 0;
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      const int kBorder = 1;
+      if (!(x >= kBorder && y >= kBorder && x < w - kBorder && y < h - kBorder)) continue;
+      uint16_t d16 = BSO_AT(uint16_t, &kf->depth, y, x);
+      if (d16 & BSLAM_INVALID_DEPTH_BIT) continue;
+      uint8_t* occ = &occupied[(size_t)(y / cell) * cw + (x / cell)];
+      if (*occ) continue;
+      *occ = 1;
+      if (*surfels_size + created >= max_surfels) continue;   /* BS/kernel_create_surfels.cc:162-165 logs and skips */
+      uint32_t si = *surfels_size + created;
+      ++created;
+      float calibrated_depth = bso_raw_to_calibrated_depth(dp->a, BSO_AT(float, &dp->cfactor_buffer, y / cell, x / cell), dp->raw_to_float_depth, d16);
+      bso_f3 gp = bso_mul34(&global_T_frame_m, bso_unproject(&unproj, x, y, calibrated_depth));
+      bso_surfel_set_position(surfels, si, gp);
+      bso_f3 ln = bso_u16_to_image_space_normal(BSO_AT(uint16_t, &kf->normals, y, x));
+      bso_f3 gn = bso_rotate34(&global_T_frame_m, ln);
+      bso_surfel_set_normal(surfels, si, gn);
+      float radius_squared = half_to_float(BSO_AT(uint16_t, &kf->radius, y, x));
+      BSO_AT(float, surfels, BSLAM_SURFEL_RADIUS_SQUARED, si) = radius_squared;
+      bso_f2 pc = {x + 0.5f, y + 0.5f};
+      bso_f2 color_pxy;
+      bso_depth_to_color_pxy(pc, &d2c, &color_pxy);
+      /* colour: tex2D<float4> at color_pxy, stored as u8 (rgb); the path never reads it back,
+       * nearest texel is used here (the reference interpolates). */
+      int cxi = (int)fminf(fmaxf(color_pxy.x, 0.f), (float)(kf->color.width - 1));
+      int cyi = (int)fminf(fmaxf(color_pxy.y, 0.f), (float)(kf->color.height - 1));
+      const uint8_t* cp = (const uint8_t*)kf->color.address + (size_t)cyi * kf->color.pitch + 4 * (size_t)cxi;
+      uint8_t col[4] = {cp[0], cp[1], cp[2], 0};
+      memcpy(&BSO_AT(float, surfels, BSLAM_SURFEL_COLOR, si), col, 4);
+      bso_f2 t1, t2;
+      /* note: the UNQUANTISED global normal gn is used here, as in the reference (:124-131) */
+      bso_tangent_projections(gp, gn, radius_squared, &kf->frame_T_global, color_camera->fx, color_camera->fy, color_camera->cx, color_camera->cy, &t1, &t2);
+      float d1, d2;
+      bso_raw_descriptor_residual(&kf->color, tex_mode, color_pxy, t1, t2, 0, 0, &d1, &d2);
+      BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR1, si) = d1;
+      BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR2, si) = d2;
+    }
+  }
+  free(occupied);
+  *surfels_size += created;
+  return created;
+}

@@ -1,0 +1,356 @@
+"""Test-side binding of the ORACLE (oracle/libbslam_oracle.so) and host scene containers.
+
+Test infrastructure only: the product package (badslam_amd) never imports this.
+Host buffers are numpy arrays; `HostScene.to_device()` uploads them into torch CUDA
+tensors and returns the same POD views pointing at device memory, so the HIP path
+and the oracle see identical bytes.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from badslam_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libbslam_oracle.so")
+
+P = C.POINTER
+_CAM, _DP, _BUF, _KFS = P(abi.Camera4f), P(abi.DepthParams), P(abi.Buffer2D), P(abi.KeyframeView)
+
+
+def build_oracle():
+    """Compiles the oracle's C restatement with gcc (oracle/Makefile)."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    L = C.CDLL(ORACLE_SO)
+    f32p, u32p, f64p = P(C.c_float), P(C.c_uint32), P(C.c_double)
+    sig = {
+        "bso_se3_identity": (None, [P(abi.SE3f)]),
+        "bso_se3_exp": (None, [f32p, P(abi.SE3f)]),
+        "bso_se3_log": (None, [P(abi.SE3f), f32p]),
+        "bso_se3_mul": (None, [P(abi.SE3f), P(abi.SE3f), P(abi.SE3f)]),
+        "bso_se3_inverse": (None, [P(abi.SE3f), P(abi.SE3f)]),
+        "bso_se3_matrix3x4": (None, [P(abi.SE3f), P(abi.Mat3x4)]),
+        "bso_keyframe_set_pose": (None, [_KFS, P(abi.SE3f)]),
+        "bso_is_scale1_pose_estimation_converged": (C.c_int, [f32p]),
+        "bso_solve_ldlt_upper": (None, [C.c_int, f32p, f32p, f32p]),
+        "bso_association": (None, [_CAM, _DP, _KFS, C.c_uint32, _BUF, u32p]),
+        "bso_accumulate_pose_estimation_coeffs": (None, [
+            C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, P(abi.Mat3x4), C.c_uint32, _BUF,
+            C.c_int, u32p, f32p, f32p, f32p, f64p, f64p, f32p]),
+        "bso_estimate_frame_pose": (None, [
+            C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, P(abi.SE3f), C.c_uint32, _BUF,
+            C.c_int, C.c_int, P(abi.SE3f), P(C.c_int), P(C.c_int)]),
+        "bso_update_surfel_activation": (None, [_CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
+        "bso_update_surfel_normals": (None, [_CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
+        "bso_optimize_geometry_iteration": (None, [
+            C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF, C.c_int]),
+        "bso_pcg_init": (None, [P(abi.PCGLayout), _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(abi.PCGVectors), C.c_int]),
+        "bso_pcg_init2": (None, [P(abi.PCGLayout), C.c_float, P(abi.PCGVectors)]),
+        "bso_pcg_step1": (None, [P(abi.PCGLayout), _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(abi.PCGVectors), C.c_int, C.c_int]),
+        "bso_pcg_step2": (None, [P(abi.PCGLayout), P(abi.PCGVectors), f32p]),
+        "bso_pcg_step3": (None, [P(abi.PCGLayout), P(abi.PCGVectors)]),
+        "bso_update_surfels_from_pcg_delta": (None, [C.c_uint32, _BUF, C.c_int, C.c_uint32, f32p]),
+        "bso_update_cfactors_from_pcg_delta": (None, [_BUF, C.c_uint32, f32p]),
+        "bso_compute_brightness": (None, [C.c_int, C.c_int, C.c_void_p, _BUF]),
+        "bso_preprocess_depth": (None, [_CAM, _DP, _BUF, _BUF, _BUF, _BUF, f32p, f32p]),
+        "bso_create_surfels_for_keyframe": (C.c_uint32, [_CAM, _CAM, _DP, _KFS, P(abi.SE3f), u32p, C.c_uint32, _BUF, C.c_int]),
+        "bso_bench_pose_pass": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, C.c_int, f32p, u32p, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+# ----------------------------------------------------------------------------- helpers
+
+def np_buffer2d(arr):
+    """bslam_buffer2d over a C-contiguous 2-D (or [h, w, 4] uint8) numpy array."""
+    assert arr.flags["C_CONTIGUOUS"]
+    h, w = arr.shape[0], arr.shape[1]
+    return abi.Buffer2D(arr.ctypes.data, h, w, arr.strides[0])
+
+
+def fptr(arr):
+    return arr.ctypes.data_as(P(C.c_float))
+
+
+def make_camera(fx, fy, cx, cy, width, height):
+    return abi.Camera4f(fx, fy, cx, cy, width, height)
+
+
+def se3_identity():
+    T = abi.SE3f()
+    lib().bso_se3_identity(C.byref(T))
+    return T
+
+
+def se3_exp(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    T = abi.SE3f()
+    lib().bso_se3_exp(fptr(x), C.byref(T))
+    return T
+
+
+def se3_log(T):
+    out = np.zeros(6, np.float32)
+    lib().bso_se3_log(C.byref(T), fptr(out))
+    return out
+
+
+def se3_mul(a, b):
+    T = abi.SE3f()
+    lib().bso_se3_mul(C.byref(a), C.byref(b), C.byref(T))
+    return T
+
+
+def se3_inverse(a):
+    T = abi.SE3f()
+    lib().bso_se3_inverse(C.byref(a), C.byref(T))
+    return T
+
+
+def se3_copy(a):
+    T = abi.SE3f()
+    C.memmove(C.byref(T), C.byref(a), C.sizeof(abi.SE3f))
+    return T
+
+
+def se3_matrix3x4(a):
+    M = abi.Mat3x4()
+    lib().bso_se3_matrix3x4(C.byref(a), C.byref(M))
+    return M
+
+
+def se3_to_np(a):
+    return np.array(list(a.q) + list(a.t), np.float32)
+
+
+class HostKeyframe:
+    """Host mirror of vis::Keyframe's buffers (BS/keyframe.h:227-231)."""
+
+    def __init__(self, depth, normals, radius, color, global_T_frame, kf_id=0, activation=abi.KF_ACTIVE,
+                 min_depth=0.0, max_depth=0.0):
+        self.depth, self.normals, self.radius, self.color = depth, normals, radius, color
+        self.global_T_frame = se3_copy(global_T_frame)
+        self.id = kf_id
+        self.activation = activation
+        self.min_depth, self.max_depth = min_depth, max_depth
+
+    def view(self, bufs=None):
+        """bslam_keyframe_view over host memory (or over `bufs`, 4 Buffer2D of device memory)."""
+        v = abi.KeyframeView()
+        if bufs is None:
+            v.depth, v.normals = np_buffer2d(self.depth), np_buffer2d(self.normals)
+            v.radius, v.color = np_buffer2d(self.radius), np_buffer2d(self.color)
+        else:
+            v.depth, v.normals, v.radius, v.color = bufs
+        lib().bso_keyframe_set_pose(C.byref(v), C.byref(self.global_T_frame))
+        v.activation = self.activation
+        v.id = self.id
+        return v
+
+
+class HostScene:
+    """Host mirror of the DirectBA scene state (BS/direct_ba.h: surfels_, active_surfels_,
+    cfactor_buffer_, depth_params_, cameras, keyframes_)."""
+
+    def __init__(self, color_camera, depth_camera, raw_to_float_depth, baseline_fx, cell, max_surfels,
+                 use_depth_residuals=True, use_descriptor_residuals=False, tex_mode=abi.TEX_FIXED_POINT_1_8):
+        self.color_camera, self.depth_camera = color_camera, depth_camera
+        w, h = depth_camera.width, depth_camera.height
+        self.cfactor = np.zeros(((h - 1) // cell + 1, (w - 1) // cell + 1), np.float32)
+        self.a = 0.0
+        self.raw_to_float_depth, self.baseline_fx, self.cell = raw_to_float_depth, baseline_fx, cell
+        self.max_surfels = max_surfels
+        self.surfels = np.zeros((abi.SURFEL_ATTRIBUTE_COUNT, max_surfels), np.float32)
+        self.active = np.zeros((1, max_surfels), np.uint8)
+        self.surfels_size = 0
+        self.keyframes = []
+        self.use_depth_residuals = use_depth_residuals
+        self.use_descriptor_residuals = use_descriptor_residuals
+        self.tex_mode = tex_mode
+
+    # --- POD views over host memory
+    def depth_params(self, cfactor_buf=None):
+        dp = abi.DepthParams()
+        dp.cfactor_buffer = np_buffer2d(self.cfactor) if cfactor_buf is None else cfactor_buf
+        dp.a = self.a
+        dp.raw_to_float_depth = self.raw_to_float_depth
+        dp.baseline_fx = self.baseline_fx
+        dp.sparse_surfel_cell_size = self.cell
+        return dp
+
+    def surfel_buf(self):
+        return np_buffer2d(self.surfels)
+
+    def active_buf(self):
+        return np_buffer2d(self.active)
+
+    def keyframe_views(self):
+        arr = (abi.KeyframeView * max(1, len(self.keyframes)))()
+        for i, kf in enumerate(self.keyframes):
+            arr[i] = kf.view()
+        return arr
+
+    # --- scene construction through the oracle's restatement of the producers
+    def add_keyframe_from_images(self, depth_u16, rgb_u8, global_T_frame):
+        """Keyframe(stream, frame_index, depth_params, depth_camera, depth_image, color_image, pose)
+        (BS/keyframe.cc:82-161) followed by DirectBA::AddKeyframe (BS/direct_ba.cc:196-204)."""
+        L = lib()
+        h, w = depth_u16.shape
+        depth_in = np.ascontiguousarray(depth_u16, np.uint16)
+        depth = np.zeros((h, w), np.uint16)
+        normals = np.zeros((h, w), np.uint16)
+        radius = np.zeros((h, w), np.uint16)
+        color = np.zeros((h, w, 4), np.uint8)
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        cb = np_buffer2d(color)
+        L.bso_compute_brightness(w, h, rgb.ctypes.data, C.byref(cb))
+        dp = self.depth_params()
+        mn, mx = C.c_float(), C.c_float()
+        bi, bd, bn, br = np_buffer2d(depth_in), np_buffer2d(depth), np_buffer2d(normals), np_buffer2d(radius)
+        L.bso_preprocess_depth(C.byref(self.depth_camera), C.byref(dp), C.byref(bi), C.byref(bd), C.byref(bn), C.byref(br),
+                               C.byref(mn), C.byref(mx))
+        kf = HostKeyframe(depth, normals, radius, color, global_T_frame, kf_id=len(self.keyframes),
+                          min_depth=mn.value, max_depth=mx.value)
+        self.keyframes.append(kf)
+        return kf
+
+    def create_surfels_for_keyframe(self, kf):
+        """DirectBA::CreateSurfelsForKeyframe(filter_new_surfels=false) (BS/direct_ba.cc:340-405)."""
+        L = lib()
+        dp = self.depth_params()
+        v = kf.view()
+        size = C.c_uint32(self.surfels_size)
+        sb = self.surfel_buf()
+        n = L.bso_create_surfels_for_keyframe(C.byref(self.color_camera), C.byref(self.depth_camera), C.byref(dp), C.byref(v),
+                                              C.byref(kf.global_T_frame), C.byref(size), self.max_surfels, C.byref(sb),
+                                              self.tex_mode)
+        self.active[0, self.surfels_size:size.value] = abi.BSLAM_SURFEL_ACTIVE_FLAG
+        self.surfels_size = size.value
+        return n
+
+    # --- oracle calls on the host state
+    def association(self, kf):
+        out = np.zeros(max(1, self.surfels_size), np.uint32)
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        lib().bso_association(C.byref(self.depth_camera), C.byref(dp), C.byref(v), self.surfels_size, C.byref(sb),
+                              out.ctypes.data_as(P(C.c_uint32)))
+        return out[:self.surfels_size]
+
+    def accumulate_pose(self, kf, frame_T_global=None, per_surfel=False, use_depth=None, use_desc=None):
+        use_depth = self.use_depth_residuals if use_depth is None else use_depth
+        use_desc = self.use_descriptor_residuals if use_desc is None else use_desc
+        H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+        H64, b64 = np.zeros(21, np.float64), np.zeros(6, np.float64)
+        ps = np.zeros((max(1, self.surfels_size), 8), np.float32) if per_surfel else None
+        cnt, cost = C.c_uint32(), C.c_float()
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        M = v.frame_T_global if frame_T_global is None else frame_T_global
+        lib().bso_accumulate_pose_estimation_coeffs(
+            int(use_depth), int(use_desc), C.byref(self.color_camera), C.byref(self.depth_camera), C.byref(dp),
+            C.byref(v.depth), C.byref(v.normals), C.byref(v.color), C.byref(M), self.surfels_size, C.byref(sb),
+            self.tex_mode, C.byref(cnt), C.byref(cost), fptr(H), fptr(b),
+            H64.ctypes.data_as(P(C.c_double)), b64.ctypes.data_as(P(C.c_double)),
+            fptr(ps) if ps is not None else None)
+        return dict(H=H, b=b, H64=H64, b64=b64, count=cnt.value, cost=cost.value,
+                    per_surfel=None if ps is None else ps[:self.surfels_size])
+
+    def estimate_frame_pose(self, kf, initial, max_iterations=30):
+        out = abi.SE3f()
+        it, conv = C.c_int(), C.c_int()
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        lib().bso_estimate_frame_pose(
+            int(self.use_depth_residuals), int(self.use_descriptor_residuals), C.byref(self.color_camera),
+            C.byref(self.depth_camera), C.byref(dp), C.byref(v.depth), C.byref(v.normals), C.byref(v.color),
+            C.byref(initial), self.surfels_size, C.byref(sb), self.tex_mode, max_iterations,
+            C.byref(out), C.byref(it), C.byref(conv))
+        return out, it.value, bool(conv.value)
+
+    def update_activation(self):
+        dp, sb, ab, kfs = self.depth_params(), self.surfel_buf(), self.active_buf(), self.keyframe_views()
+        lib().bso_update_surfel_activation(C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs,
+                                           self.surfels_size, C.byref(sb), C.byref(ab))
+
+    def update_normals(self):
+        dp, sb, ab, kfs = self.depth_params(), self.surfel_buf(), self.active_buf(), self.keyframe_views()
+        lib().bso_update_surfel_normals(C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs,
+                                        self.surfels_size, C.byref(sb), C.byref(ab))
+
+    def optimize_geometry_iteration(self):
+        dp, sb, ab, kfs = self.depth_params(), self.surfel_buf(), self.active_buf(), self.keyframe_views()
+        lib().bso_optimize_geometry_iteration(
+            int(self.use_depth_residuals), int(self.use_descriptor_residuals), C.byref(self.color_camera),
+            C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs, self.surfels_size, C.byref(sb), C.byref(ab),
+            self.tex_mode)
+
+    # --- upload
+    def to_device(self, device="cuda:0"):
+        return DeviceScene(self, device)
+
+
+class DeviceScene:
+    """The same scene in HBM: torch tensors own the memory, POD views point into them."""
+
+    def __init__(self, host, device):
+        import torch
+        self.torch = torch
+        self.host = host
+        self.device = device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.surfels = t(host.surfels)
+        self.active = t(host.active)
+        self.cfactor = t(host.cfactor)
+        self.kf_tensors = []
+        for kf in host.keyframes:
+            self.kf_tensors.append((t(kf.depth.view(np.int16)), t(kf.normals.view(np.int16)), t(kf.radius.view(np.int16)), t(kf.color)))
+        self.surfels_size = host.surfels_size
+
+    @staticmethod
+    def tbuf(tensor, h=None, w=None):
+        h = tensor.shape[0] if h is None else h
+        w = tensor.shape[1] if w is None else w
+        return abi.Buffer2D(tensor.data_ptr(), h, w, tensor.stride(0) * tensor.element_size())
+
+    def depth_params(self):
+        return self.host.depth_params(self.tbuf(self.cfactor))
+
+    def surfel_buf(self):
+        return self.tbuf(self.surfels)
+
+    def active_buf(self):
+        return self.tbuf(self.active)
+
+    def keyframe_view(self, i):
+        d, n, r, c = self.kf_tensors[i]
+        return self.host.keyframes[i].view((self.tbuf(d), self.tbuf(n), self.tbuf(r), self.tbuf(c)))
+
+    def keyframe_views(self):
+        arr = (abi.KeyframeView * max(1, len(self.kf_tensors)))()
+        for i in range(len(self.kf_tensors)):
+            arr[i] = self.keyframe_view(i)
+        return arr
+
+    def surfels_np(self):
+        return self.surfels.cpu().numpy()
+
+    def active_np(self):
+        return self.active.cpu().numpy()
