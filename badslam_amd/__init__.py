@@ -1,0 +1,67 @@
+"""badslam_amd -- MI355X-native bundle-adjustment hot path of BAD SLAM behind a C ABI.
+
+`lib()` loads the in-tree HIP library (libbadslam_hip.so, built by badslam_amd/build.py).
+There is no CPU fallback: if the library is missing or no GPU is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbadslam_hip.so")
+
+_lib = None
+
+
+class BadSlamError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libbadslam_hip.so and applies the signatures of include/badslam_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BadSlamError(
+            f"{LIB_PATH} is missing: build it with `python -m badslam_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in abi.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise BadSlamError(f"bslam error {rc}: {lib().bslam_last_error().decode()}")
+
+
+class Context:
+    """RAII wrapper of bslam_context."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        check(lib().bslam_create(device, C.byref(self._ctx)))
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def set_texture_mode(self, mode):
+        check(lib().bslam_set_texture_mode(self._ctx, mode))
+
+    def close(self):
+        if self._ctx:
+            lib().bslam_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -86,6 +86,10 @@ SIGNATURES = {
     "bslam_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
     "bslam_destroy": (C.c_int, [C.c_void_p]),
     "bslam_set_texture_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_profile_read": (C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_float)]),
+    "bslam_debug_count_pairs": (C.c_int, [
+        C.c_void_p, C.c_void_p, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(C.c_uint64), P(C.c_uint64)]),
     "bslam_accumulate_pose_estimation_coeffs": (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, P(Mat3x4),
         C.c_uint32, _BUF, C.c_int, P(C.c_uint32), P(C.c_float), P(C.c_float), P(C.c_float)]),
@@ -103,6 +107,8 @@ SIGNATURES = {
         C.c_void_p, C.c_void_p, C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
     "bslam_debug_association": (C.c_int, [
         C.c_void_p, C.c_void_p, _CAM, _DP, _KFS, C.c_uint32, _BUF, C.c_void_p]),
+    "bslam_debug_pose_residuals": (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_int, C.c_int, _CAM, _CAM, _DP, _KFS, C.c_uint32, _BUF, C.c_void_p]),
     "bslam_pcg_init": (C.c_int, [
         C.c_void_p, C.c_void_p, P(PCGLayout), _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(PCGVectors)]),
     "bslam_pcg_init2": (C.c_int, [C.c_void_p, C.c_void_p, P(PCGLayout), C.c_float, P(PCGVectors)]),

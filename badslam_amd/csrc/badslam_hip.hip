@@ -1,0 +1,541 @@
+// badslam_hip.hip -- C ABI entry points (include/badslam_hip.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "context.hpp"
+#include "geometry_kernels.hpp"
+#include "pcg_kernels.hpp"
+#include "pose_kernels.hpp"
+
+namespace bslam {
+
+thread_local std::string g_last_error;
+
+// ---- host-side construction of the kernel constants -------------------------------------------
+// Same formulas, in fp32, as the reference's factories: CreatePixelCornerProjector,
+// CreatePixelCenterUnprojector, CreateDepthToColorPixelCorner (BS/surfel_projection.h:42-124).
+// Compiled with -ffp-contract=off like everything else in this library.
+static CamConsts make_cam_consts(const bslam_context* ctx, const bslam_camera4f* color, const bslam_camera4f* depth,
+                                 const bslam_depth_params* dp) {
+  CamConsts c;
+  std::memset(&c, 0, sizeof(c));
+  c.fx = depth->fx; c.fy = depth->fy; c.cx = depth->cx; c.cy = depth->cy;
+  c.width = depth->width; c.height = depth->height;
+  c.fx_inv = 1.0f / depth->fx;
+  c.fy_inv = 1.0f / depth->fy;
+  const float cx_pixel_center = depth->cx - 0.5f;
+  const float cy_pixel_center = depth->cy - 0.5f;
+  c.cx_inv = -cx_pixel_center * c.fx_inv;
+  c.cy_inv = -cy_pixel_center * c.fy_inv;
+  if (color) {
+    c.d2c_fx = color->fx / depth->fx;
+    c.d2c_cx = -1 * color->fx * depth->cx / depth->fx + color->cx;
+    c.d2c_fy = color->fy / depth->fy;
+    c.d2c_cy = -1 * color->fy * depth->cy / depth->fy + color->cy;
+    c.color_width = color->width; c.color_height = color->height;
+    c.cfx = color->fx; c.cfy = color->fy; c.ccx = color->cx; c.ccy = color->cy;
+  }
+  c.a = dp->a;
+  c.raw_to_float_depth = dp->raw_to_float_depth;
+  c.baseline_fx = dp->baseline_fx;
+  c.cell = dp->sparse_surfel_cell_size;
+  c.cfactor = (const float*)dp->cfactor_buffer.address;
+  c.cfactor_pitch = (uint32_t)dp->cfactor_buffer.pitch;
+  c.cfactor_width = dp->cfactor_buffer.width;
+  c.tex_mode = ctx->tex_mode;
+  return c;
+}
+
+static void fill_kf(KfDev* d, const bslam_buffer2d* depth, const bslam_buffer2d* normals, const bslam_buffer2d* color,
+                    const bslam_mat3x4* frame_T_global, const bslam_mat3x3* global_R_frame, int activation, int id) {
+  std::memset(d, 0, sizeof(*d));
+  d->depth = (const uint8_t*)depth->address;     d->depth_pitch = (uint32_t)depth->pitch;
+  d->normals = (const uint8_t*)normals->address; d->normals_pitch = (uint32_t)normals->pitch;
+  if (color) { d->color = (const uint8_t*)color->address; d->color_pitch = (uint32_t)color->pitch; }
+  std::memcpy(d->frame_T_global.m, frame_T_global->m, sizeof(float) * 12);
+  if (global_R_frame) std::memcpy(d->global_R_frame, global_R_frame->m, sizeof(float) * 9);
+  d->activation = activation;
+  d->id = id;
+}
+
+static int check_common(const bslam_context* ctx, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+                        const bslam_buffer2d* surfels) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  if (!depth_camera || !dp || !surfels) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if (dp->sparse_surfel_cell_size < 1) return fail(BSLAM_ERR_INVALID_ARGUMENT, "sparse_surfel_cell_size must be >= 1");
+  if (!dp->cfactor_buffer.address) return fail(BSLAM_ERR_INVALID_ARGUMENT, "cfactor_buffer is null");
+  const int need_w = (depth_camera->width - 1) / dp->sparse_surfel_cell_size + 1;
+  const int need_h = (depth_camera->height - 1) / dp->sparse_surfel_cell_size + 1;
+  if (dp->cfactor_buffer.width < need_w || dp->cfactor_buffer.height < need_h)
+    return fail(BSLAM_ERR_INVALID_ARGUMENT, "cfactor_buffer is %dx%d, camera %dx%d at cell %d needs %dx%d",
+                dp->cfactor_buffer.width, dp->cfactor_buffer.height, depth_camera->width, depth_camera->height,
+                dp->sparse_surfel_cell_size, need_w, need_h);
+  if (surfels->height < BSLAM_SURFEL_DATA_ATTRIBUTE_COUNT) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfel buffer has %d rows, need >= %d", surfels->height, BSLAM_SURFEL_DATA_ATTRIBUTE_COUNT);
+  return BSLAM_OK;
+}
+
+static int check_image(const bslam_buffer2d* b, const bslam_camera4f* cam, size_t elem, const char* name) {
+  if (!b || !b->address) return fail(BSLAM_ERR_INVALID_ARGUMENT, "%s buffer is null", name);
+  if (b->width != cam->width || b->height != cam->height)
+    return fail(BSLAM_ERR_INVALID_ARGUMENT, "%s buffer is %dx%d but the camera is %dx%d", name, b->width, b->height, cam->width, cam->height);
+  if (b->pitch < (size_t)b->width * elem) return fail(BSLAM_ERR_INVALID_ARGUMENT, "%s pitch %zu too small", name, b->pitch);
+  return BSLAM_OK;
+}
+
+static SurfelRows surfel_rows(const bslam_buffer2d* s, uint32_t size) {
+  auto row = [&](int r) { return (const float*)((const uint8_t*)s->address + (size_t)r * s->pitch); };
+  SurfelRows o;
+  o.x = row(BSLAM_SURFEL_X); o.y = row(BSLAM_SURFEL_Y); o.z = row(BSLAM_SURFEL_Z);
+  o.normal = (const uint32_t*)row(BSLAM_SURFEL_NORMAL);
+  o.radius_squared = row(BSLAM_SURFEL_RADIUS_SQUARED);
+  o.d1 = row(BSLAM_SURFEL_DESCRIPTOR1); o.d2 = row(BSLAM_SURFEL_DESCRIPTOR2);
+  o.size = size;
+  return o;
+}
+
+static SurfelRowsRW surfel_rows_rw(const bslam_buffer2d* s, const bslam_buffer2d* active, uint32_t size) {
+  auto row = [&](int r) { return (float*)((uint8_t*)s->address + (size_t)r * s->pitch); };
+  SurfelRowsRW o;
+  o.x = row(BSLAM_SURFEL_X); o.y = row(BSLAM_SURFEL_Y); o.z = row(BSLAM_SURFEL_Z);
+  o.normal = (uint32_t*)row(BSLAM_SURFEL_NORMAL);
+  o.radius_squared = row(BSLAM_SURFEL_RADIUS_SQUARED);
+  o.d1 = row(BSLAM_SURFEL_DESCRIPTOR1); o.d2 = row(BSLAM_SURFEL_DESCRIPTOR2);
+  o.active = active ? (uint8_t*)active->address : nullptr;
+  o.size = size;
+  return o;
+}
+
+// Uploads a keyframe table through pinned staging.  The staging buffer is only rewritten after
+// the previous upload has been consumed (stream-ordered, so we wait for the stream first if the
+// same staging is still in flight -- uploads are a few KB and the wait is normally a no-op).
+static int upload_kf_table(bslam_context* ctx, hipStream_t stream, const std::vector<KfDev>& table) {
+  const size_t bytes = table.size() * sizeof(KfDev);
+  int rc = ctx->kf_table.reserve(bytes);
+  if (rc) return rc;
+  rc = ctx->staging.reserve(bytes);
+  if (rc) return rc;
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  std::memcpy(ctx->staging.ptr, table.data(), bytes);
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, ctx->staging.ptr, bytes, hipMemcpyHostToDevice, stream));
+  return BSLAM_OK;
+}
+
+static int build_kf_table(const bslam_camera4f* depth_camera, const bslam_camera4f* color_camera, bool need_color,
+                          int keyframe_count, const bslam_keyframe_view* keyframes, std::vector<KfDev>* table) {
+  table->resize((size_t)keyframe_count);
+  for (int k = 0; k < keyframe_count; ++k) {
+    const bslam_keyframe_view& v = keyframes[k];
+    int rc = check_image(&v.depth, depth_camera, 2, "keyframe depth");
+    if (rc) return rc;
+    rc = check_image(&v.normals, depth_camera, 2, "keyframe normals");
+    if (rc) return rc;
+    if (need_color) {
+      rc = check_image(&v.color, color_camera, 4, "keyframe color");
+      if (rc) return rc;
+    }
+    fill_kf(&(*table)[k], &v.depth, &v.normals, need_color ? &v.color : nullptr, &v.frame_T_global, &v.global_R_frame, v.activation, v.id);
+  }
+  return BSLAM_OK;
+}
+
+// Chooses how many keyframes one block walks: enough blocks to fill 256 CUs several times over.
+static int choose_kfs_per_block(int tiles, int kf_count) {
+  const int target_blocks = 8192;
+  int chunks = (target_blocks + tiles - 1) / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > kf_count) chunks = kf_count;
+  return (kf_count + chunks - 1) / chunks;
+}
+
+static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
+                                  int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
+                                  int* tiles_out) {
+  const int tiles = (int)((surfels_size + kPoseTile - 1) / kPoseTile);
+  *tiles_out = tiles;
+  int rc = ctx->partials.reserve((size_t)tiles * kf_count * kRow * sizeof(float));
+  if (rc) return rc;
+  rc = ctx->coeffs.reserve((size_t)kf_count * kRow * sizeof(float));
+  if (rc) return rc;
+  const int per_block = choose_kfs_per_block(tiles, kf_count);
+  dim3 grid((unsigned)tiles, (unsigned)((kf_count + per_block - 1) / per_block));
+  const SurfelRows rows = surfel_rows(surfels, surfels_size);
+  const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
+  float* partials = (float*)ctx->partials.ptr;
+  {
+  ProfScope prof(ctx, stream);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
+  }
+  BSLAM_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count), dim3(256), 0, stream, partials, tiles, kf_count, (float*)ctx->coeffs.ptr, states);
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+}  // namespace bslam
+
+using namespace bslam;
+
+extern "C" {
+
+int bslam_abi_version(void) { return 1; }
+
+const char* bslam_last_error(void) { return g_last_error.c_str(); }
+
+int bslam_create(int device, bslam_context** out_ctx) {
+  if (!out_ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "out_ctx is null");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(BSLAM_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU fallback", hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(BSLAM_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, count);
+  BSLAM_HIP_TRY(hipSetDevice(device));
+  bslam_context* ctx = new (std::nothrow) bslam_context();
+  if (!ctx) return fail(BSLAM_ERR_OUT_OF_MEMORY, "out of host memory");
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  int rc = ctx->misc.reserve(256);
+  if (rc) { delete ctx; return rc; }
+  *out_ctx = ctx;
+  return BSLAM_OK;
+}
+
+int bslam_destroy(bslam_context* ctx) {
+  if (!ctx) return BSLAM_OK;
+  hipError_t e = hipSetDevice(ctx->device); (void)e;
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release();
+  ctx->staging.release(); ctx->staging2.release();
+  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(ev);
+  for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
+  delete ctx;
+  return BSLAM_OK;
+}
+
+int bslam_set_texture_mode(bslam_context* ctx, int mode) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  if (mode != BSLAM_TEX_FIXED_POINT_1_8 && mode != BSLAM_TEX_EXACT_FLOAT) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown texture mode %d", mode);
+  ctx->tex_mode = mode;
+  return BSLAM_OK;
+}
+
+int bslam_profile_enable(bslam_context* ctx, int enable) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->profiling = enable != 0;
+  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(ev);
+  ctx->prof_pending.clear();
+  ctx->prof_launches = 0;
+  ctx->prof_ms = 0.f;
+  return BSLAM_OK;
+}
+
+int bslam_profile_read(bslam_context* ctx, int32_t* launches, float* total_ms) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  for (auto& ev : ctx->prof_pending) {
+    BSLAM_HIP_TRY(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    BSLAM_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    ctx->prof_ms += ms;
+    ctx->prof_launches += 1;
+    ctx->prof_pool.push_back(ev);
+  }
+  ctx->prof_pending.clear();
+  if (launches) *launches = ctx->prof_launches;
+  if (total_ms) *total_ms = ctx->prof_ms;
+  ctx->prof_launches = 0;
+  ctx->prof_ms = 0.f;
+  return BSLAM_OK;
+}
+
+int bslam_debug_count_pairs(
+    bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    uint64_t* in_bounds_pairs, uint64_t* associated_pairs) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (keyframe_count <= 0 || !keyframes) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need at least one keyframe");
+  if (surfels_size == 0 || surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad surfels_size %u", surfels_size);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, nullptr, false, keyframe_count, keyframes, &table))) return rc;
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  unsigned long long* d_out = (unsigned long long*)((uint8_t*)ctx->misc.ptr + 64);
+  BSLAM_HIP_TRY(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(count_pairs_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+                     surfel_rows_rw(surfels, nullptr, surfels_size), d_out);
+  BSLAM_HIP_TRY(hipGetLastError());
+  if ((rc = ctx->staging2.reserve(64))) return rc;
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, d_out, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  const unsigned long long* o = (const unsigned long long*)ctx->staging2.ptr;
+  if (in_bounds_pairs) *in_bounds_pairs = o[0];
+  if (associated_pairs) *associated_pairs = o[1];
+  return BSLAM_OK;
+}
+
+int bslam_accumulate_pose_estimation_coeffs(
+    bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer, const bslam_buffer2d* color_buffer,
+    const bslam_mat3x4* frame_T_global_estimate, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int debug, uint32_t* residual_count, float* residual_sum, float* H, float* b) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  // CHECK(use_depth_residuals || use_descriptor_residuals); CHECK_GT(surfels_size, 0)  (BS/kernel_opt_pose.cc:58-61)
+  if (!use_depth_residuals && !use_descriptor_residuals) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need depth and/or descriptor residuals");
+  if (surfels_size == 0) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size must be > 0");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  if (!H || !b || !frame_T_global_estimate || !color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if ((rc = check_image(depth_buffer, depth_camera, 2, "depth"))) return rc;
+  if ((rc = check_image(normals_buffer, depth_camera, 2, "normals"))) return rc;
+  if (use_descriptor_residuals && (rc = check_image(color_buffer, color_camera, 4, "color"))) return rc;
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+
+  std::vector<KfDev> table(1);
+  fill_kf(&table[0], depth_buffer, normals_buffer, use_descriptor_residuals ? color_buffer : nullptr, frame_T_global_estimate, nullptr, BSLAM_KF_ACTIVE, 0);
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  int tiles = 0;
+  if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, 1, surfels_size, surfels, nullptr, &tiles))) return rc;
+  if ((rc = ctx->staging2.reserve(kRow * sizeof(float)))) return rc;
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, ctx->coeffs.ptr, kRow * sizeof(float), hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));   // results valid on return, BS/kernel_opt_pose.cc:96
+  const float* out = (const float*)ctx->staging2.ptr;
+  std::memcpy(H, out, 21 * sizeof(float));
+  std::memcpy(b, out + 21, 6 * sizeof(float));
+  if (debug) {
+    if (residual_sum) *residual_sum = out[kRowCost];
+    if (residual_count) std::memcpy(residual_count, out + kRowCount, sizeof(uint32_t));
+  }
+  return BSLAM_OK;
+}
+
+int bslam_accumulate_pose_coeffs_batched(
+    bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    float* Hb, uint32_t* counts) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (!use_depth_residuals && !use_descriptor_residuals) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need depth and/or descriptor residuals");
+  if (keyframe_count <= 0 || !keyframes || !color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need at least one keyframe");
+  if (surfels_size == 0) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size must be > 0");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, color_camera, use_descriptor_residuals != 0, keyframe_count, keyframes, &table))) return rc;
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  int tiles = 0;
+  if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, nullptr, &tiles))) return rc;
+  if (Hb || counts) {
+    const size_t bytes = (size_t)keyframe_count * kRow * sizeof(float);
+    if ((rc = ctx->staging2.reserve(bytes))) return rc;
+    BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, ctx->coeffs.ptr, bytes, hipMemcpyDeviceToHost, stream));
+    BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+    const float* out = (const float*)ctx->staging2.ptr;
+    for (int k = 0; k < keyframe_count; ++k) {
+      if (Hb) std::memcpy(Hb + 27 * (size_t)k, out + (size_t)k * kRow, 27 * sizeof(float));
+      if (counts) std::memcpy(&counts[k], out + (size_t)k * kRow + kRowCount, sizeof(uint32_t));
+    }
+  }
+  return BSLAM_OK;
+}
+
+int bslam_estimate_frame_poses_batched(
+    bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    int max_iterations, bslam_se3f* poses, int32_t* iterations_done, int32_t* converged,
+    bslam_allreduce_fn allreduce, void* allreduce_user) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (!use_depth_residuals && !use_descriptor_residuals) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need depth and/or descriptor residuals");
+  if (keyframe_count <= 0 || !keyframes || !poses || !color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need at least one keyframe and its pose");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, color_camera, use_descriptor_residuals != 0, keyframe_count, keyframes, &table))) return rc;
+  // pose state: keyframes that are INACTIVE are not optimised (BS/direct_ba_alternating.cc:549-552)
+  std::vector<PoseState> states((size_t)keyframe_count);
+  for (int k = 0; k < keyframe_count; ++k) {
+    PoseState& st = states[k];
+    std::memset(&st, 0, sizeof(st));
+    std::memcpy(st.q, poses[k].q, sizeof(float) * 4);
+    std::memcpy(st.t, poses[k].t, sizeof(float) * 3);
+    st.converged = (keyframes[k].activation == BSLAM_KF_INACTIVE) ? 1 : 0;
+  }
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const size_t state_bytes = states.size() * sizeof(PoseState);
+  if ((rc = ctx->pose_state.reserve(state_bytes))) return rc;
+  if ((rc = ctx->staging2.reserve(state_bytes + 64))) return rc;
+  std::memcpy(ctx->staging2.ptr, states.data(), state_bytes);
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->pose_state.ptr, ctx->staging2.ptr, state_bytes, hipMemcpyHostToDevice, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  PoseState* d_states = (PoseState*)ctx->pose_state.ptr;
+  int* d_active = (int*)ctx->misc.ptr;
+  int* h_active = (int*)((uint8_t*)ctx->staging2.ptr + state_bytes);
+
+  for (int it = 0; it < max_iterations; ++it) {
+    BSLAM_HIP_TRY(hipMemsetAsync(d_active, 0, sizeof(int), stream));
+    if (surfels_size > 0) {
+      int tiles = 0;
+      if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles))) return rc;
+    } else {
+      if ((rc = ctx->coeffs.reserve((size_t)keyframe_count * kRow * sizeof(float)))) return rc;
+      BSLAM_HIP_TRY(hipMemsetAsync(ctx->coeffs.ptr, 0, (size_t)keyframe_count * kRow * sizeof(float), stream));   // H.setZero(); b.setZero() (:147-149)
+    }
+    if (allreduce) {
+      // converged keyframes keep stale rows; they are identical on every rank because every rank
+      // applied identical updates, and the solve kernel ignores them.
+      const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
+      if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
+    }
+    hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
+                       (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active);
+    BSLAM_HIP_TRY(hipGetLastError());
+    BSLAM_HIP_TRY(hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+    BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+    if (*h_active == 0) break;
+  }
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, d_states, state_bytes, hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  const PoseState* out = (const PoseState*)ctx->staging2.ptr;
+  for (int k = 0; k < keyframe_count; ++k) {
+    std::memcpy(poses[k].q, out[k].q, sizeof(float) * 4);
+    std::memcpy(poses[k].t, out[k].t, sizeof(float) * 3);
+    if (iterations_done) iterations_done[k] = out[k].iterations;
+    if (converged) converged[k] = (keyframes[k].activation == BSLAM_KF_INACTIVE) ? 1 : out[k].converged;
+  }
+  return BSLAM_OK;
+}
+
+// ---- activation / geometry ------------------------------------------------------------------
+
+static int geometry_common(bslam_context* ctx, hipStream_t stream, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+                           const bslam_depth_params* dp, bool need_color, int keyframe_count, const bslam_keyframe_view* keyframes,
+                           uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active) {
+  int rc = check_common(ctx, depth_camera, dp, surfels);
+  if (rc) return rc;
+  if (keyframe_count < 0 || (keyframe_count > 0 && !keyframes)) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad keyframe list");
+  if (!active || !active->address) return fail(BSLAM_ERR_INVALID_ARGUMENT, "active_surfels is null");
+  if (surfels_size > (uint32_t)surfels->width || surfels_size > (uint32_t)active->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds a buffer width", surfels_size);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, color_camera, need_color, keyframe_count, keyframes, &table))) return rc;
+  if (table.empty()) table.resize(1);   // keep the table pointer valid; kf_count = 0 makes every loop empty
+  return upload_kf_table(ctx, stream, table);
+}
+
+int bslam_update_surfel_activation(
+    bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (surfels_size == 0) return BSLAM_OK;   // BS/kernel_surfel_activation.cc:48-50
+  int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
+  if (rc) return rc;
+  const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  hipLaunchKernelGGL(activation_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+                     surfel_rows_rw(surfels, active_surfels, surfels_size));
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+int bslam_update_surfel_normals(
+    bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (surfels_size == 0) return BSLAM_OK;   // BS/kernel_opt_geometry.cc:48-50
+  int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
+  if (rc) return rc;
+  const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  hipLaunchKernelGGL((geometry_kernel<0, true>), dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+                     surfel_rows_rw(surfels, active_surfels, surfels_size));
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+int bslam_optimize_geometry_iteration(
+    bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    const bslam_buffer2d* active_surfels) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!use_depth_residuals && !use_descriptor_residuals) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need depth and/or descriptor residuals");   // BS/kernel_opt_geometry.cc:91
+  if (surfels_size == 0) return BSLAM_OK;   // BS/kernel_opt_geometry.cc:93-95
+  if (!color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "color_camera is null");
+  int rc = geometry_common(ctx, stream, color_camera, depth_camera, depth_params, use_descriptor_residuals != 0, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
+  if (rc) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  const dim3 grid((surfels_size + 255) / 256), block(256);
+  const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
+  const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
+  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_kernel<1, true>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
+  else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
+  else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+int bslam_debug_association(
+    bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    const bslam_keyframe_view* keyframe, uint32_t surfels_size, const bslam_buffer2d* surfels, uint32_t* out_pixel) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (surfels_size == 0) return BSLAM_OK;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (!keyframe || !out_pixel) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, nullptr, false, 1, keyframe, &table))) return rc;
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  hipLaunchKernelGGL(association_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr,
+                     surfel_rows_rw(surfels, nullptr, surfels_size), out_pixel);
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+int bslam_debug_pose_residuals(
+    bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    const bslam_keyframe_view* keyframe, uint32_t surfels_size, const bslam_buffer2d* surfels, float* out) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (surfels_size == 0) return BSLAM_OK;
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (!keyframe || !out || !color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, color_camera, use_descriptor_residuals != 0, 1, keyframe, &table))) return rc;
+  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  const dim3 grid((surfels_size + 255) / 256), block(256);
+  const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
+  const SurfelRowsRW rows = surfel_rows_rw(surfels, nullptr, surfels_size);
+  if (use_depth_residuals && use_descriptor_residuals) hipLaunchKernelGGL((residual_probe_kernel<true, true>), grid, block, 0, stream, c, kfs, rows, out);
+  else if (use_depth_residuals) hipLaunchKernelGGL((residual_probe_kernel<true, false>), grid, block, 0, stream, c, kfs, rows, out);
+  else hipLaunchKernelGGL((residual_probe_kernel<false, true>), grid, block, 0, stream, c, kfs, rows, out);
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
+}  // extern "C"
+
+#include "pcg_abi.inc"

@@ -1,0 +1,104 @@
+// context.hpp -- host-side context of libbadslam_hip: scratch slabs, keyframe table upload,
+// error reporting.  Plays the role of the reference's PoseEstimationHelperBuffers /
+// IntrinsicsOptimizationHelperBuffers (BS/kernels.h:46-89): scratch is allocated once and
+// re-used, launch paths never allocate unless a slab has to grow.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "device_math.hpp"
+
+namespace bslam {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define BSLAM_HIP_TRY(expr)                                                                         \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return ::bslam::fail(BSLAM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// A device slab that only ever grows.
+struct Slab {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return BSLAM_OK;
+    if (ptr) { hipError_t e = hipFree(ptr); (void)e; ptr = nullptr; bytes = 0; }
+    size_t want = need + need / 4 + 256;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) return fail(BSLAM_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    bytes = want;
+    return BSLAM_OK;
+  }
+  void release() { if (ptr) { hipError_t e = hipFree(ptr); (void)e; } ptr = nullptr; bytes = 0; }
+};
+
+struct PinnedSlab {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return BSLAM_OK;
+    if (ptr) { hipError_t e = hipHostFree(ptr); (void)e; ptr = nullptr; bytes = 0; }
+    size_t want = need + need / 4 + 256;
+    hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(BSLAM_ERR_OUT_OF_MEMORY, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    bytes = want;
+    return BSLAM_OK;
+  }
+  void release() { if (ptr) { hipError_t e = hipHostFree(ptr); (void)e; } ptr = nullptr; bytes = 0; }
+};
+
+}  // namespace bslam
+
+struct bslam_context {
+  int device = 0;
+  int tex_mode = BSLAM_TEX_FIXED_POINT_1_8;
+  int cu_count = 256;
+  bslam::Slab kf_table;      // KfDev[K]
+  bslam::Slab partials;      // float[tiles][K][32]
+  bslam::Slab coeffs;        // float[K][32]
+  bslam::Slab pose_state;    // PoseState[K]
+  bslam::Slab misc;          // small device scalars
+  bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
+  bslam::PinnedSlab staging2;
+  // kernel timing (bslam_profile_*)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  int prof_launches = 0;
+  float prof_ms = 0.f;
+};
+
+namespace bslam {
+// Brackets one kernel launch with events when profiling is on.
+struct ProfScope {
+  bslam_context* ctx; hipStream_t stream; std::pair<hipEvent_t, hipEvent_t> ev; bool on;
+  ProfScope(bslam_context* c, hipStream_t s) : ctx(c), stream(s), on(c->profiling) {
+    if (!on) return;
+    if (!ctx->prof_pool.empty()) { ev = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+    else { hipError_t e = hipEventCreate(&ev.first); e = hipEventCreate(&ev.second); (void)e; }
+    hipError_t e = hipEventRecord(ev.first, stream); (void)e;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipError_t e = hipEventRecord(ev.second, stream); (void)e;
+    ctx->prof_pending.push_back(ev);
+  }
+};
+}  // namespace bslam

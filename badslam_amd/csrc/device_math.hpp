@@ -1,0 +1,330 @@
+// device_math.hpp -- gfx950 device functions of the BA hot path.
+//
+// Projection, association, residuals and Jacobians of the reference's cost function,
+// written for CDNA4.  Built with -ffp-contract=off and IEEE division / sqrt so that the
+// predicate chain that decides the integer outputs (associated pixel, activation mask)
+// rounds the same way on every run and matches the CPU oracle bit for bit.
+//
+// Reference formulas: BS/ = applications/badslam/src/badslam/ of pangfumin/badslam;
+// each function names the file:line whose behaviour it reproduces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/badslam_hip.h"
+
+namespace bslam {
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ float sqlen(f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }           // BS/cuda_util.cuh:52
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // BS/cuda_util.cuh:57
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {                                                     // BS/cuda_util.cuh:78
+  return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float norm3(f3 v) { return __fsqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z); }  // BS/cuda_util.cuh:85
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 scale3(float m, f3 b) { return mk3(m * b.x, m * b.y, m * b.z); }
+
+// 3x4 rigid transform held in registers / SGPRs (= CUDAMatrix3x4, BS/cuda_matrix.cuh:98-137).
+struct M34 { float m[12]; };
+
+__device__ __forceinline__ f3 mul34(const M34& T, f3 p) {
+  return mk3(T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z + T.m[3],
+             T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z + T.m[7],
+             T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z + T.m[11]);
+}
+__device__ __forceinline__ f3 rot34(const M34& T, f3 p) {
+  return mk3(T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z,
+             T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z,
+             T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z);
+}
+
+// Per-launch camera constants, computed on the host exactly as the reference's factories do
+// (BS/surfel_projection.h:42-124) and passed by value.
+struct CamConsts {
+  // depth camera, pixel-corner projector
+  float fx, fy, cx, cy;
+  int width, height;
+  // PixelCenterUnprojector of the depth camera
+  float fx_inv, fy_inv, cx_inv, cy_inv;
+  // DepthToColorPixelCorner
+  float d2c_fx, d2c_fy, d2c_cx, d2c_cy;
+  int color_width, color_height;
+  // colour camera (corner convention; the centre projector only differs in cx, cy which are unused)
+  float cfx, cfy, ccx, ccy;
+  // DepthParameters scalars
+  float a, raw_to_float_depth, baseline_fx;
+  int cell;
+  const float* cfactor;   // device image
+  uint32_t cfactor_pitch; // bytes
+  int cfactor_width;
+  int tex_mode;
+};
+
+// Device view of one keyframe (pointers + pose), kept in a device array and read with scalar loads.
+struct KfDev {
+  const uint8_t* depth;    uint32_t depth_pitch;
+  const uint8_t* normals;  uint32_t normals_pitch;
+  const uint8_t* color;    uint32_t color_pitch;
+  M34 frame_T_global;
+  float global_R_frame[9];
+  int activation;
+  int id;
+};
+
+__device__ __forceinline__ float nx_of(const CamConsts& c, float px) { return c.fx_inv * px + c.cx_inv; }   // BS/surfel_projection.cuh:116
+__device__ __forceinline__ float ny_of(const CamConsts& c, float py) { return c.fy_inv * py + c.cy_inv; }
+__device__ __forceinline__ f3 unproject(const CamConsts& c, int x, int y, float depth) {                    // BS/surfel_projection.cuh:110
+  return mk3(depth * (c.fx_inv * x + c.cx_inv), depth * (c.fy_inv * y + c.cy_inv), depth);
+}
+__device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3 p) {                       // BS/surfel_projection.cuh:52
+  return f2{fx * (p.x / p.z) + cx, fy * (p.y / p.z) + cy};
+}
+
+// BS/util.cuh:46-53.  expf(-a * inv_depth) is exactly 1 for a == 0 (the default, no depth
+// deformation), so that case skips the transcendental without changing a bit.
+__device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint32_t measured_depth) {
+  const float inv_depth = 1.0f / (raw_to_float_depth * (float)measured_depth);
+  const float e = (a == 0.f) ? 1.0f : expf(-a * inv_depth);
+  return 1.f / (inv_depth + cfactor * e);
+}
+
+// BS/util.cuh:107-130
+__device__ __forceinline__ f3 u16_to_image_space_normal(uint32_t value) {
+  f3 r;
+  r.x = (float)(int8_t)(value & 0xff) * (1.0f / 127);
+  r.y = (float)(int8_t)((value >> 8) & 0xff) * (1.0f / 127);
+  r.z = 1 - r.x * r.x - r.y * r.y;
+  r.z = -__fsqrt_rn((r.z > 0.f) ? r.z : 0.f);
+  return r;
+}
+
+// BS/util_nvcc_only.cuh:67-95
+__device__ __forceinline__ uint32_t small_float_to_s10(float value) {
+  return 0x03ffu & (uint32_t)(uint16_t)(int16_t)(value * 511 + ((value > 0) ? 0.5f : -0.5f));
+}
+__device__ __forceinline__ float s10_to_small_float(uint32_t value) {
+  const int32_t s = ((int32_t)(value << 22)) >> 22;   // sign-extend 10 bits
+  return (float)s * (1.0f / 511);
+}
+__device__ __forceinline__ uint32_t pack_normal(f3 n) {
+  return (small_float_to_s10(n.x) << 0) | (small_float_to_s10(n.y) << 10) | (small_float_to_s10(n.z) << 20);
+}
+__device__ __forceinline__ f3 unpack_normal(uint32_t value) {
+  f3 n = mk3(s10_to_small_float(value >> 0), s10_to_small_float(value >> 10), s10_to_small_float(value >> 20));
+  const float factor = 1.0f / norm3(n);
+  return scale3(factor, n);
+}
+
+// BS/robust_weighting.cuh:39-86
+__device__ __forceinline__ float tukey_weight(float r, float k) {
+  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return t * t; }
+  return 0.f;
+}
+__device__ __forceinline__ float tukey_residual(float r, float k) {
+  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return (1 / 6.f) * k * k * (1 - t * t * t); }
+  return (1 / 6.f) * k * k;
+}
+__device__ __forceinline__ float huber_weight(float r, float k) { const float a = fabsf(r); return (a < k) ? 1.f : (k / a); }
+__device__ __forceinline__ float huber_residual(float r, float k) {
+  const float a = fabsf(r);
+  return (a < k) ? 0.5f * r * r : k * (a - 0.5f * k);
+}
+
+// BS/cost_function.cuh:44-98, 105-185
+constexpr float kDepthTukey = 10.f;
+constexpr float kDepthUncertainty = 0.1f;
+constexpr float kCosNormalCompat = 0.76604f;   // BS/kernels.cuh:58
+constexpr float kDescWeight = 1e-2f;
+constexpr float kDescHuber = 10.f;
+
+__device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
+  return (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
+}
+__device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
+  return baseline_fx / (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
+}
+__device__ __forceinline__ float depth_weight(float r) { return 1.f * tukey_weight(r, 1.f * kDepthTukey); }
+__device__ __forceinline__ float weighted_depth_residual(float r) { return 1.f * tukey_residual(r, 1.f * kDepthTukey); }
+__device__ __forceinline__ float desc_weight(float r) { return 1.f * kDescWeight * huber_weight(r, kDescHuber); }
+__device__ __forceinline__ float weighted_desc_residual(float r) { return 1.f * kDescWeight * huber_residual(r, kDescHuber); }
+
+// float -> int, truncating and saturating (v_cvt_i32_f32; CUDA's cvt.rzi.s32.f32 behaves the same)
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+
+// ---------------------------------------------------------------------------------------------
+// Colour sampling.  MI355X has no texture unit; clamp addressing, u8 -> [0,1] normalisation and
+// bilinear filtering of the reference's texture (BS/keyframe.cc:67-73) are ALU code over plain
+// global loads of the luma byte (.w of the uchar4 pixel).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float texel_w(const uint8_t* color, uint32_t pitch, int w, int h, int ix, int iy) {
+  ix = max(0, min(ix, w - 1));
+  iy = max(0, min(iy, h - 1));
+  return (float)color[(size_t)iy * pitch + 4 * (size_t)ix + 3] * (1.0f / 255.0f);
+}
+
+__device__ __forceinline__ float tex_w(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y, int mode) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (mode == BSLAM_TEX_FIXED_POINT_1_8) {
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  }
+  const int i = (int)fminf(fmaxf(fx, -2.0f), (float)w);
+  const int j = (int)fminf(fmaxf(fy, -2.0f), (float)h);
+  const float t00 = texel_w(color, pitch, w, h, i, j);
+  const float t10 = texel_w(color, pitch, w, h, i + 1, j);
+  const float t01 = texel_w(color, pitch, w, h, i, j + 1);
+  const float t11 = texel_w(color, pitch, w, h, i + 1, j + 1);
+  const float w00 = (1.0f - a) * (1.0f - b);
+  const float w10 = a * (1.0f - b);
+  const float w01 = (1.0f - a) * b;
+  const float w11 = a * b;
+  return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+}
+
+// BS/cost_function.cuh:115-136
+__device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_squared, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
+  f3 t1 = cross(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
+  t1 = scale3(__fsqrt_rn(radius_squared / fmaxf(1e-12f, sqlen(t1))), scale3(2.0f, t1));
+  *t1_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t1)));
+  f3 t2 = cross(gn, t1);
+  t2 = scale3(__fsqrt_rn(radius_squared / fmaxf(1e-12f, sqlen(t2))), scale3(2.0f, t2));
+  *t2_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t2)));
+}
+
+// BS/cost_function.cuh:140-156
+__device__ __forceinline__ void raw_descriptor_residual(const KfDev& kf, const CamConsts& c, f2 pxy, f2 t1, f2 t2, float d1, float d2, float* r1, float* r2) {
+  const float intensity = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, pxy.x, pxy.y, c.tex_mode);
+  const float i1 = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, t1.x, t1.y, c.tex_mode);
+  const float i2 = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, t2.x, t2.y, c.tex_mode);
+  *r1 = (180.f * (i1 - intensity)) - d1;
+  *r2 = (180.f * (i2 - intensity)) - d2;
+}
+
+// one block of BS/cost_function.cuh:200-239
+__device__ __forceinline__ void point_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* dx, float* dy) {
+  int ix = f2i(fmaxf(0.f, p.x - 0.5f));
+  int iy = f2i(fmaxf(0.f, p.y - 0.5f));
+  const float tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - (float)ix));
+  const float ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - (float)iy));
+  ix = min(ix, c.color_width - 1);
+  iy = min(iy, c.color_height - 1);
+  const float tl = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix, iy);
+  const float tr = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix + 1, iy);
+  const float bl = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix, iy + 1);
+  const float br = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix + 1, iy + 1);
+  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
+  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
+}
+
+// BS/cost_function.cuh:191-254 (without the three dead fetches :241-243)
+__device__ __forceinline__ void descriptor_jacobian_wrt_projected_position(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2,
+                                                                           float* gx1, float* gy1, float* gx2, float* gy2) {
+  float cdx, cdy, t1dx, t1dy, t2dx, t2dy;
+  point_gradient(kf, c, cp, &cdx, &cdy);
+  point_gradient(kf, c, t1, &t1dx, &t1dy);
+  point_gradient(kf, c, t2, &t2dx, &t2dy);
+  *gx1 = 180.f * (t1dx - cdx);
+  *gy1 = 180.f * (t1dy - cdy);
+  *gx2 = 180.f * (t2dx - cdx);
+  *gy2 = 180.f * (t2dy - cdy);
+}
+
+// BS/surfel_projection.cuh:196-207
+__device__ __forceinline__ bool depth_to_color_pxy(const CamConsts& c, f2 pxy, f2* out) {
+  out->x = c.d2c_fx * pxy.x + c.d2c_cx;
+  out->y = c.d2c_fy * pxy.y + c.d2c_cy;
+  return out->x >= 0 && out->y >= 0 && f2i(out->x) < c.color_width && f2i(out->y) < c.color_height;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projection + association (BS/surfel_projection_nvcc_only.cuh:49-127, 302-332; BS/util.cuh:67-99)
+// ---------------------------------------------------------------------------------------------
+struct Proj {
+  f3 local;        // surfel position in the keyframe
+  f3 n_local;      // surfel normal rotated into the keyframe
+  float depth;     // calibrated depth of the pixel
+  int px, py;
+  f2 pxy;
+  uint32_t pixel_normal;  // raw u16 normal of the associated pixel
+};
+
+// gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
+// associated with the pixel it projects to.
+__device__ __forceinline__ bool project_and_associate(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, Proj* r) {
+  const M34& T = kf.frame_T_global;
+  // MultiplyIfResultZIsPositive BS/cuda_matrix.cuh:113-124
+  r->local.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+  if (r->local.z <= 0.f) return false;
+  r->local.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
+  r->local.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+  // ProjectSurfelToImage BS/util.cuh:86-99
+  r->pxy = project(c.fx, c.fy, c.cx, c.cy, r->local);
+  r->px = f2i(r->pxy.x);
+  r->py = f2i(r->pxy.y);
+  if (r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height) return false;
+  // IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127
+  const uint32_t measured = *(const uint16_t*)(kf.depth + (size_t)r->py * kf.depth_pitch + 2 * (size_t)r->px);
+  if (measured & BSLAM_INVALID_DEPTH_BIT) return false;
+  const float cf = *(const float*)((const uint8_t*)c.cfactor + (size_t)(r->py / c.cell) * c.cfactor_pitch + 4 * (size_t)(r->px / c.cell));
+  r->depth = raw_to_calibrated_depth(c.a, cf, c.raw_to_float_depth, measured);
+  r->n_local = rot34(T, gn);
+  const float stddev = depth_stddev(nx_of(c, (float)r->px), ny_of(c, (float)r->py), r->depth, r->n_local, c.baseline_fx);
+  if (fabsf(r->local.z - r->depth) > kDepthTukey * stddev) return false;
+  const float dist = norm3(r->local);
+  if ((1.0f / dist) * dot(r->local, r->n_local) > 0) return false;
+  r->pixel_normal = *(const uint16_t*)(kf.normals + (size_t)r->py * kf.normals_pitch + 2 * (size_t)r->px);
+  const f3 pn = u16_to_image_space_normal(r->pixel_normal);
+  if (dot(r->n_local, pn) < kCosNormalCompat) return false;
+  return true;
+}
+
+// Depth residual and its pose Jacobian (BS/kernel_opt_pose.cu:45-94, BS/cost_function.cuh:56-88).
+__device__ __forceinline__ void depth_residual_and_jacobian(const CamConsts& c, const Proj& r, float* raw, float* J) {
+  const float inv_stddev = depth_inv_stddev(nx_of(c, (float)r.px), ny_of(c, (float)r.py), r.depth, r.n_local, c.baseline_fx);
+  const f3 lu = unproject(c, r.px, r.py, r.depth);
+  *raw = inv_stddev * dot(r.n_local, sub3(lu, r.local));
+  J[0] = inv_stddev * r.n_local.x;
+  J[1] = inv_stddev * r.n_local.y;
+  J[2] = inv_stddev * r.n_local.z;
+  J[3] = inv_stddev * (-r.n_local.y * lu.z + r.n_local.z * lu.y);
+  J[4] = inv_stddev * (r.n_local.x * lu.z - r.n_local.z * lu.x);
+  J[5] = inv_stddev * (-r.n_local.x * lu.y + r.n_local.y * lu.x);
+}
+
+// Pose Jacobian of one descriptor residual (BS/kernel_opt_pose.cu:122-141).
+__device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 ls, float* J) {
+  const float inv_ls_z = 1.f / ls.z;
+  const float ls_z_sq = ls.z * ls.z;
+  const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
+  J[0] = -gx * inv_ls_z;
+  J[1] = -gy * inv_ls_z;
+  J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
+  const float ls_x_y = ls.x * ls.y;
+  J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
+  J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
+  J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;   // valid in lane 0
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace bslam

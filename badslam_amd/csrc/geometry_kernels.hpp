@@ -1,0 +1,252 @@
+// geometry_kernels.hpp -- surfel activation, normal / position / descriptor updates (gfx950).
+//
+// Replaces the kernels of BS/kernel_surfel_activation.cu and BS/kernel_opt_geometry.cu.
+// The reference launches one kernel per keyframe and read-modify-writes the accumulator rows
+// 8-16 of the surfel SoA on every launch (32 / 16 / 64 B of avoidable traffic per pair).  Here a
+// thread owns one surfel, keeps it and its accumulators in registers and walks the keyframe
+// table in list order -- the same order in which the reference's serialised launches add their
+// terms, so the fp32 sums are formed in the reference's order -- and writes the surfel back
+// once.  Scratch rows 8-16 are never touched.
+#pragma once
+
+#include "device_math.hpp"
+
+namespace bslam {
+
+struct SurfelRowsRW {
+  float* x; float* y; float* z;
+  uint32_t* normal;
+  const float* radius_squared;
+  float* d1; float* d2;
+  uint8_t* active;
+  uint32_t size;
+};
+
+// SetSurfelInactiveKernel + K x DetermineActiveSurfelsKernel (BS/kernel_surfel_activation.cu:38-79)
+__global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.size) return;
+  uint8_t flag = s.active[i] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
+  const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+  const f3 gn = unpack_normal(s.normal[i]);
+  for (int k = 0; k < kf_count; ++k) {
+    const KfDev& kf = kfs[k];
+    if (kf.activation != BSLAM_KF_ACTIVE) continue;
+    Proj p;
+    if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; break; }
+  }
+  s.active[i] = flag;
+}
+
+// Association probe: out[i] = py * width + px or 0xffffffff.
+__global__ __launch_bounds__(256) void association_kernel(CamConsts c, const KfDev* __restrict__ kfs, SurfelRowsRW s, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.size) return;
+  const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+  const f3 gn = unpack_normal(s.normal[i]);
+  Proj p;
+  out[i] = project_and_associate(c, kfs[0], gp, gn, &p) ? (uint32_t)(p.py * c.width + p.px) : 0xffffffffu;
+}
+
+// Census: pairs passing z > 0 and bounds, and associated pairs (roofline accounting).
+__global__ __launch_bounds__(256) void count_pairs_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s,
+                                                          unsigned long long* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t inb = 0, assoc = 0;
+  if (i < s.size) {
+    const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+    const f3 gn = unpack_normal(s.normal[i]);
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev& kf = kfs[k];
+      const M34& T = kf.frame_T_global;
+      f3 l;
+      l.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+      if (l.z <= 0.f) continue;
+      l.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
+      l.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+      const f2 pxy = project(c.fx, c.fy, c.cx, c.cy, l);
+      if (pxy.x < 0 || pxy.y < 0 || f2i(pxy.x) >= c.width || f2i(pxy.y) >= c.height) continue;
+      inb += 1;
+      Proj p;
+      if (project_and_associate(c, kf, gp, gn, &p)) assoc += 1;
+    }
+  }
+  inb = wave_sum_u32(inb);
+  assoc = wave_sum_u32(assoc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)inb);
+    atomicAdd(&out[1], (unsigned long long)assoc);
+  }
+}
+
+// Per-surfel residual probe for one keyframe (parity aid): out[i*8 + ...] =
+// [depth raw residual, depth weight, desc r1, desc w1, desc r2, desc w2, flags, 0].
+template <bool kDepth, bool kDesc>
+__global__ __launch_bounds__(256) void residual_probe_kernel(CamConsts c, const KfDev* __restrict__ kfs, SurfelRowsRW s, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.size) return;
+  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+  const f3 gn = unpack_normal(s.normal[i]);
+  const KfDev& kf = kfs[0];
+  Proj p;
+  if (project_and_associate(c, kf, gp, gn, &p)) {
+    uint32_t flags = 1;
+    float J[6];
+    if (kDepth) {
+      float raw;
+      depth_residual_and_jacobian(c, p, &raw, J);
+      o[0] = raw; o[1] = depth_weight(raw);
+    }
+    if (kDesc) {
+      f2 color_pxy;
+      if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
+        f2 t1, t2;
+        tangent_projections(gp, gn, s.radius_squared[i], kf.frame_T_global, c, &t1, &t2);
+        float r1, r2;
+        raw_descriptor_residual(kf, c, color_pxy, t1, t2, s.d1[i], s.d2[i], &r1, &r2);
+        o[2] = r1; o[3] = desc_weight(r1); o[4] = r2; o[5] = desc_weight(r2);
+        flags |= 2;
+      }
+    }
+    o[6] = (float)flags;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = o[k];
+}
+
+// Geometry step of one BA iteration for one surfel.
+//   kMode 0: normals only                  (UpdateSurfelNormalsCUDA, BS/kernel_opt_geometry.cc:39-78)
+//   kMode 1: normals, then position        (geometry-only,  BS/kernel_opt_geometry.cc:137-169)
+//   kMode 2: normals, then position + descriptors jointly   (BS/kernel_opt_geometry.cc:170-200)
+template <int kMode, bool kDepth>
+__global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.size) return;
+  if (!(s.active[i] & BSLAM_SURFEL_ACTIVE_FLAG)) return;
+  f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+  uint32_t packed = s.normal[i];
+  f3 gn = unpack_normal(packed);
+
+  // ---- normals: mean of the associated pixel normals, rotated to global
+  // (BS/kernel_opt_geometry.cu:527-557, 577-597)
+  {
+    float sx = 0, sy = 0, sz = 0, cnt = 0;
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev& kf = kfs[k];
+      if (kf.activation == BSLAM_KF_INACTIVE) continue;
+      Proj p;
+      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
+      const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+      const float* R = kf.global_R_frame;
+      sx += R[0] * ln.x + R[1] * ln.y + R[2] * ln.z;
+      sy += R[3] * ln.x + R[4] * ln.y + R[5] * ln.z;
+      sz += R[6] * ln.x + R[7] * ln.y + R[8] * ln.z;
+      cnt += 1.f;
+    }
+    if (cnt >= 1) {
+      const float inv = 1.f / cnt;
+      packed = pack_normal(mk3(inv * sx, inv * sy, inv * sz));
+      s.normal[i] = packed;
+      gn = unpack_normal(packed);
+    }
+  }
+  if (kMode == 0) return;
+
+  if (kMode == 1) {
+    // ---- position along the normal from depth residuals (BS/kernel_opt_geometry.cu:417-459, 487-507)
+    float H = 0, b = 0;
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev& kf = kfs[k];
+      if (kf.activation == BSLAM_KF_INACTIVE) continue;
+      Proj p;
+      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
+      const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, p.n_local, c.baseline_fx);
+      const float dj = -inv_stddev;
+      const f3 lu = unproject(c, p.px, p.py, p.depth);
+      const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+      const float w = depth_weight(raw);
+      const float wj = w * dj;
+      H += wj * dj;
+      b += wj * raw;
+    }
+    if (H > 1e-6f) {
+      const float t = -1.f * b / H;
+      gp = add3(gp, scale3(t, gn));
+      s.x[i] = gp.x; s.y[i] = gp.y; s.z[i] = gp.z;
+    }
+    return;
+  }
+
+  if (kMode == 2) {
+    // ---- joint position + descriptor step (BS/kernel_opt_geometry.cu:118-231, 273-361)
+    float A0 = 0, A1 = 0, A2 = 0, A3 = 0, A5 = 0, A6 = 0, A7 = 0, A8 = 0;   // A4 = H(1,2) is never accumulated (quirk Q2)
+    const float r2 = s.radius_squared[i];
+    const float desc1 = s.d1[i], desc2 = s.d2[i];
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev& kf = kfs[k];
+      if (kf.activation == BSLAM_KF_INACTIVE) continue;
+      Proj p;
+      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
+      const f3 rn = p.n_local;
+      if (kDepth) {
+        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
+        const float dj = -inv_stddev;
+        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float w = depth_weight(raw);
+        A0 += w * dj * dj;
+        A6 += w * raw * dj;
+      }
+      f2 color_pxy;
+      if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
+        f2 t1, t2;
+        tangent_projections(gp, gn, r2, kf.frame_T_global, c, &t1, &t2);
+        float r1, rr2;
+        raw_descriptor_residual(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2);
+        float gx1, gy1, gx2, gy2;
+        descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+        const float term1 = -c.cfx * (rn.x * p.local.z - rn.z * p.local.x);
+        const float term2 = -c.cfy * (rn.y * p.local.z - rn.z * p.local.y);
+        const float term3 = 1.f / (p.local.z * p.local.z);
+        const float jp1 = -(gx1 * term1 + gy1 * term2) * term3;
+        const float jp2 = -(gx2 * term1 + gy2 * term2) * term3;
+        const float jd = -1.f;
+        const float w1 = desc_weight(r1);
+        const float wr1 = w1 * r1;
+        const float w2 = desc_weight(rr2);
+        const float wr2 = w2 * rr2;
+        A0 += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        A1 += w1 * jp1 * jd;
+        A3 += w1 * jd * jd;
+        A6 += wr1 * jp1 + wr2 * jp2;
+        A7 += wr1 * jd;
+        A2 += w2 * jp2 * jd;
+        A5 += w2 * jd * jd;
+        A8 += wr2 * jd;
+      }
+    }
+    float H00 = A0, H01 = A1, H02 = A2, H11 = A3, H12 = 0.f, H22 = A5;
+    H00 += 1e-6f; H11 += 1e-6f; H22 += 1e-6f;
+    H00 = __fsqrt_rn(H00);
+    H01 = H01 / H00;
+    H11 = __fsqrt_rn(H11 - H01 * H01);
+    H02 = H02 / H00;
+    H12 = (H12 - H02 * H01) / H11;
+    H22 = __fsqrt_rn(H22 - H02 * H02 - H12 * H12);
+    const float y0 = A6 / H00;
+    const float y1 = (A7 - H01 * y0) / H11;
+    const float y2 = (A8 - H02 * y0 - H12 * y1) / H22;
+    const float x2 = y2 / H22;
+    const float x1 = (y1 - H12 * x2) / H11;
+    const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
+    if (x0 != 0) {
+      gp = sub3(gp, scale3(x0, gn));
+      s.x[i] = gp.x; s.y[i] = gp.y; s.z[i] = gp.z;
+    }
+    if (x1 != 0) s.d1[i] = fmaxf(-180.f, fminf(180.f, desc1 - x1));
+    if (x2 != 0) s.d2[i] = fmaxf(-180.f, fminf(180.f, desc2 - x2));
+  }
+}
+
+}  // namespace bslam

@@ -1,0 +1,349 @@
+// pose_kernels.hpp -- pose Gauss-Newton kernels (gfx950).
+//
+// Replaces AccumulatePoseEstimationCoeffsCUDAKernel + AccumulateGaussNewtonHAndB
+// (BS/kernel_opt_pose.cu:251-383, BS/gauss_newton.cuh:47-95) and the host part of
+// DirectBA::EstimateFramePose (BS/direct_ba_alternating.cc:130-233).
+//
+// MI355X design (not the reference's one-launch-per-keyframe, 27-block-reductions-per-launch
+// shape):
+//   * one launch covers (surfel tiles) x (keyframe chunks); a thread keeps kR surfels in
+//     registers (position + decoded normal) and walks the keyframes of its chunk, so surfel
+//     bytes are read once per chunk instead of once per keyframe;
+//   * the 21 + 6 (+ cost, count) coefficients are accumulated per thread over its kR surfels,
+//     reduced across the wave with shuffles and across the 4 waves through LDS, and written as
+//     one 32-float row per (tile, keyframe); a second kernel sums the rows over tiles in a
+//     fixed order: deterministic, no float atomics;
+//   * the 6x6 solve, SE3 update and convergence test run on the device (one thread per
+//     keyframe), all keyframes advance in lock-step.
+#pragma once
+
+#include "device_math.hpp"
+
+namespace bslam {
+
+constexpr int kPoseThreads = 256;
+constexpr int kPoseR = 4;                      // surfels per thread
+constexpr int kPoseTile = kPoseThreads * kPoseR;
+constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
+constexpr int kRowCost = 27;
+constexpr int kRowCount = 28;
+
+struct SurfelRows {
+  const float* x; const float* y; const float* z;
+  const uint32_t* normal;
+  const float* radius_squared;
+  const float* d1; const float* d2;
+  uint32_t size;
+};
+
+struct PoseState {
+  float q[4];
+  float t[3];
+  int converged;     // 1 = no further iterations
+  int iterations;
+  int pad[3];
+};
+
+__device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* J, float* acc) {
+  // BS/gauss_newton.cuh:60-91: H[idx] += (w * J[row]) * J[col]; b[i] += (w * raw) * J[i]
+  int idx = 0;
+#pragma unroll
+  for (int row = 0; row < 6; ++row) {
+#pragma unroll
+    for (int col = row; col < 6; ++col) {
+      acc[idx] += w * J[row] * J[col];
+      ++idx;
+    }
+  }
+  const float wr = w * raw;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] += wr * J[i];
+}
+
+template <bool kDepth, bool kDesc>
+__global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block,
+    SurfelRows s, float* __restrict__ partials, const PoseState* __restrict__ states) {
+  const int tile = blockIdx.x;
+  const int kf_begin = blockIdx.y * kfs_per_block;
+  const int kf_end = min(kf_count, kf_begin + kfs_per_block);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  __shared__ float red[2][kPoseThreads / 64][kRow];
+
+  // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
+  f3 gp[kPoseR], gn[kPoseR];
+  bool valid[kPoseR];
+  float r2[kPoseR], d1[kPoseR], d2[kPoseR];
+#pragma unroll
+  for (int r = 0; r < kPoseR; ++r) {
+    const uint32_t i = (uint32_t)tile * kPoseTile + r * kPoseThreads + threadIdx.x;
+    valid[r] = i < s.size;
+    const uint32_t j = valid[r] ? i : 0;
+    gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
+    gn[r] = unpack_normal(s.normal[j]);
+    if (kDesc) { r2[r] = s.radius_squared[j]; d1[r] = s.d1[j]; d2[r] = s.d2[j]; }
+  }
+
+  int parity = 0;
+  for (int k = kf_begin; k < kf_end; ++k) {
+    if (states != nullptr && states[k].converged) continue;   // uniform
+    const KfDev& kf = kfs[k];
+    float acc[kRowCost + 1];
+#pragma unroll
+    for (int i = 0; i <= kRowCost; ++i) acc[i] = 0.f;
+    uint32_t count = 0;
+
+#pragma unroll
+    for (int r = 0; r < kPoseR; ++r) {
+      Proj p;
+      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      float J[6];
+      float raw;
+      if (kDepth) {                                           // BS/kernel_opt_pose.cu:283-317
+        depth_residual_and_jacobian(c, p, &raw, J);
+        accumulate_h_b(raw, depth_weight(raw), J, acc);
+        acc[kRowCost] += weighted_depth_residual(raw);
+        count += 1;
+      }
+      if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
+        f2 color_pxy;
+        if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
+          f2 t1, t2;
+          tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
+          float r1, rr2;
+          raw_descriptor_residual(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2);
+          float gx1, gy1, gx2, gy2;
+          descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+          gx1 *= c.cfx; gx2 *= c.cfx;
+          gy1 *= c.cfy; gy2 *= c.cfy;
+          descriptor_pose_jacobian(gx1, gy1, p.local, J);
+          accumulate_h_b(r1, desc_weight(r1), J, acc);
+          descriptor_pose_jacobian(gx2, gy2, p.local, J);
+          accumulate_h_b(rr2, desc_weight(rr2), J, acc);
+          acc[kRowCost] += weighted_desc_residual(r1);        // quirk Q1: only the first residual is counted
+          count += 1;
+        }
+      }
+    }
+
+    // wave reduction (skipped when the whole wave saw nothing for this keyframe)
+    const bool any = __any(count != 0);
+    if (any) {
+#pragma unroll
+      for (int i = 0; i <= kRowCost; ++i) acc[i] = wave_sum(acc[i]);
+      count = wave_sum_u32(count);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i <= kRowCost; ++i) red[parity][wave][i] = any ? acc[i] : 0.f;
+      red[parity][wave][kRowCount] = __uint_as_float(any ? count : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kRow) {
+      float v = 0.f;
+      if (threadIdx.x < kRowCount) {
+        v = ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x];
+      } else if (threadIdx.x == kRowCount) {
+        v = __uint_as_float(__float_as_uint(red[parity][0][kRowCount]) + __float_as_uint(red[parity][1][kRowCount]) +
+                            __float_as_uint(red[parity][2][kRowCount]) + __float_as_uint(red[parity][3][kRowCount]));
+      }
+      partials[((size_t)tile * kf_count + k) * kRow + threadIdx.x] = v;
+    }
+    parity ^= 1;   // double-buffered LDS: one barrier per keyframe
+  }
+}
+
+// Sums the partial rows of one keyframe over all tiles in a fixed order.
+// grid = K, block = 256: thread t owns column t % 32 and tile residue t / 32.
+__global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restrict__ partials, int tiles, int kf_count,
+                                                           float* __restrict__ coeffs, const PoseState* __restrict__ states) {
+  const int k = blockIdx.x;
+  if (states != nullptr && states[k].converged) return;
+  const int col = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;   // 0..7
+  __shared__ float sm[8][kRow];
+  float v = 0.f;
+  uint32_t n = 0;
+  for (int t = sub; t < tiles; t += 8) {
+    const float p = partials[((size_t)t * kf_count + k) * kRow + col];
+    if (col == kRowCount) n += __float_as_uint(p); else v += p;
+  }
+  sm[sub][col] = (col == kRowCount) ? __uint_as_float(n) : v;
+  __syncthreads();
+  if (threadIdx.x < kRow) {
+    if (col == kRowCount) {
+      uint32_t total = 0;
+      for (int i = 0; i < 8; ++i) total += __float_as_uint(sm[i][col]);
+      coeffs[(size_t)k * kRow + col] = __uint_as_float(total);
+    } else {
+      float total = 0.f;
+      for (int i = 0; i < 8; ++i) total += sm[i][col];
+      coeffs[(size_t)k * kRow + col] = total;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE3 (Sophus::SE3f semantics: unit quaternion + translation, fp32) and the 6x6 solve
+// ---------------------------------------------------------------------------------------------
+struct Quat { float x, y, z, w; };
+
+__device__ __forceinline__ Quat qmul(Quat a, Quat b) {   // Eigen quat_product
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+__device__ __forceinline__ f3 qrot(Quat q, f3 v) {       // Eigen QuaternionBase::_transformVector
+  f3 qv = mk3(q.x, q.y, q.z);
+  f3 uv = mk3(qv.y * v.z - qv.z * v.y, qv.z * v.x - qv.x * v.z, qv.x * v.y - qv.y * v.x);
+  uv = add3(uv, uv);
+  f3 cx = mk3(qv.y * uv.z - qv.z * uv.y, qv.z * uv.x - qv.x * uv.z, qv.x * uv.y - qv.y * uv.x);
+  return mk3(v.x + q.w * uv.x + cx.x, v.y + q.w * uv.y + cx.y, v.z + q.w * uv.z + cx.z);
+}
+__device__ __forceinline__ void qmat(Quat q, float* R) { // Eigen QuaternionBase::toRotationMatrix
+  const float tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
+  const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+  R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
+}
+
+// SE3::exp (sophus/se3.hpp:293-313, so3.hpp:282-318)
+__device__ inline void se3_exp(const float* a, Quat* q_out, f3* t_out) {
+  const float kEps = 1e-5f;
+  const f3 omega = mk3(a[3], a[4], a[5]);
+  const float theta_sq = sqlen(omega);
+  const float theta = __fsqrt_rn(theta_sq);
+  const float half_theta = 0.5f * theta;
+  float imag_factor, real_factor;
+  if (theta < kEps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+    real_factor = 1.f - 0.5f * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    imag_factor = sinf(half_theta) / theta;
+    real_factor = cosf(half_theta);
+  }
+  Quat q{imag_factor * omega.x, imag_factor * omega.y, imag_factor * omega.z, real_factor};
+  const float O[9] = {0.f, -omega.z, omega.y, omega.z, 0.f, -omega.x, -omega.y, omega.x, 0.f};
+  float O2[9];
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc) O2[3 * r + cc] = O[3 * r + 0] * O[0 + cc] + O[3 * r + 1] * O[3 + cc] + O[3 * r + 2] * O[6 + cc];
+  float V[9];
+  if (theta < kEps) {
+    qmat(q, V);
+  } else {
+    const float c1 = (1.f - cosf(theta)) / (theta_sq);
+    const float c2 = (theta - sinf(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; ++i) {
+      const float id = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+      V[i] = (id + c1 * O[i]) + c2 * O2[i];
+    }
+  }
+  *q_out = q;
+  *t_out = mk3(V[0] * a[0] + V[1] * a[1] + V[2] * a[2], V[3] * a[0] + V[4] * a[1] + V[5] * a[2], V[6] * a[0] + V[7] * a[1] + V[8] * a[2]);
+}
+
+// T <- T * D (SE3Base::operator*=, SO3Base::operator*= with the first-order renormalisation)
+__device__ inline void se3_mul_inplace(Quat* q, f3* t, Quat dq, f3 dt) {
+  const f3 rt = qrot(*q, dt);
+  *t = mk3(t->x + rt.x, t->y + rt.y, t->z + rt.z);
+  Quat r = qmul(*q, dq);
+  const float sn = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+  if (sn != 1.0f) {
+    const float f = 2.0f / (1.0f + sn);
+    r.x *= f; r.y *= f; r.z *= f; r.w *= f;
+  }
+  *q = r;
+}
+
+// frame_T_global = global_T_frame.inverse().matrix3x4()
+__device__ inline void se3_inverse_matrix(Quat q, f3 t, float* m /*12*/) {
+  const Quat qi{-q.x, -q.y, -q.z, q.w};
+  const f3 ti = qrot(qi, mk3(t.x * -1.f, t.y * -1.f, t.z * -1.f));
+  float R[9];
+  qmat(qi, R);
+  for (int r = 0; r < 3; ++r) { m[4 * r] = R[3 * r]; m[4 * r + 1] = R[3 * r + 1]; m[4 * r + 2] = R[3 * r + 2]; }
+  m[3] = ti.x; m[7] = ti.y; m[11] = ti.z;
+}
+
+// 6x6 symmetric solve in double: LDL^T with diagonal pivoting (what Eigen's
+// selfadjointView<Upper>().ldlt().solve() does at BS/direct_ba_alternating.cc:206).
+__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x) {
+  constexpr int n = 6;
+  double A[36];
+  int idx = 0;
+  for (int r = 0; r < n; ++r)
+    for (int cc = r; cc < n; ++cc) { A[r * n + cc] = (double)H_upper[idx]; A[cc * n + r] = (double)H_upper[idx]; ++idx; }
+  int perm[n];
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double biggest = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i) { const double v = fabs(A[i * n + i]); if (v > biggest) { biggest = v; p = i; } }
+    perm[k] = p;
+    if (p != k) {
+      for (int cc = 0; cc < n; ++cc) { const double tmp = A[k * n + cc]; A[k * n + cc] = A[p * n + cc]; A[p * n + cc] = tmp; }
+      for (int r = 0; r < n; ++r) { const double tmp = A[r * n + k]; A[r * n + k] = A[r * n + p]; A[r * n + p] = tmp; }
+    }
+    double temp[n];
+    for (int j = 0; j < k; ++j) temp[j] = A[j * n + j] * A[k * n + j];
+    double acc = 0.0;
+    for (int j = 0; j < k; ++j) acc += A[k * n + j] * temp[j];
+    const double dk = A[k * n + k] - acc;
+    A[k * n + k] = dk;
+    for (int i = k + 1; i < n; ++i) {
+      double sacc = 0.0;
+      for (int j = 0; j < k; ++j) sacc += A[i * n + j] * temp[j];
+      const double v = A[i * n + k] - sacc;
+      A[i * n + k] = (fabs(dk) > 0.0) ? v / dk : 0.0;
+    }
+  }
+  double y[n];
+  for (int i = 0; i < n; ++i) y[i] = (double)b[i];
+  for (int k = 0; k < n; ++k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) { const double d = A[i * n + i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
+  for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
+  for (int k = n - 1; k >= 0; --k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
+  for (int i = 0; i < n; ++i) x[i] = (float)y[i];
+}
+
+// One Gauss-Newton update per keyframe (BS/direct_ba_alternating.cc:206-233).
+__global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count, PoseState* __restrict__ states,
+                                  KfDev* __restrict__ kfs, int* __restrict__ active_count) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= kf_count) return;
+  PoseState st = states[k];
+  if (st.converged) return;
+  float H[21], b[6], x[6];
+  for (int i = 0; i < 21; ++i) H[i] = coeffs[(size_t)k * kRow + i];
+  for (int i = 0; i < 6; ++i) b[i] = coeffs[(size_t)k * kRow + 21 + i];
+  solve_ldlt6(H, b, x);
+  float neg[6];
+  for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
+  Quat dq; f3 dt;
+  se3_exp(neg, &dq, &dt);
+  Quat q{st.q[0], st.q[1], st.q[2], st.q[3]};
+  f3 t = mk3(st.t[0], st.t[1], st.t[2]);
+  se3_mul_inplace(&q, &t, dq, dt);
+  // IsScale1PoseEstimationConverged BS/convergence_analysis.h:45-52
+  const float sc = 1e-06f / 1e-07f;
+  float nrm = 0.f;
+  for (int i = 0; i < 6; ++i) { const float v = (i < 3) ? x[i] : x[i] * sc; nrm += v * v; }
+  st.q[0] = q.x; st.q[1] = q.y; st.q[2] = q.z; st.q[3] = q.w;
+  st.t[0] = t.x; st.t[1] = t.y; st.t[2] = t.z;
+  st.iterations += 1;
+  st.converged = (nrm < 1e-06f) ? 1 : 0;
+  states[k] = st;
+  se3_inverse_matrix(q, t, kfs[k].frame_T_global.m);
+  if (!st.converged) atomicAdd(active_count, 1);
+}
+
+}  // namespace bslam

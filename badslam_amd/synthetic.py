@@ -1,0 +1,232 @@
+"""Synthetic 640x480 keyframe stacks for bench.py: random planes, a
+photo-consistent texture, keyframe poses T0 * exp(xi), cell-4 surfel creation from every
+keyframe without merging (19 200 surfels per keyframe).
+
+Pure numpy input synthesis in the formats the hot path reads (BS/kernels.cuh:38-93,
+BS/util.cuh:105-130); it does not go through the reference's
+preprocessing kernels and it never touches oracle/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+def so3_exp(w):
+    w = np.asarray(w, np.float64)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], np.float64)
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def se3_exp(x):
+    """Returns (R, t) of exp(x), x = [translation(3), rotation(3)] (Sophus tangent order)."""
+    x = np.asarray(x, np.float64)
+    w = x[3:]
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], np.float64)
+    R = so3_exp(w)
+    if th < 1e-12:
+        V = np.eye(3) + 0.5 * K
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return R, V @ x[:3]
+
+
+def rot_to_quat(R):
+    """Unit quaternion (x, y, z, w) of a rotation matrix."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    return q / np.linalg.norm(q)
+
+
+def make_se3f(R, t):
+    T = abi.SE3f()
+    q = rot_to_quat(R)
+    for i in range(4):
+        T.q[i] = float(q[i])
+    for i in range(3):
+        T.t[i] = float(t[i])
+    return T
+
+
+def mat3x4(R, t):
+    M = abi.Mat3x4()
+    A = np.concatenate([R, t.reshape(3, 1)], axis=1).astype(np.float32)
+    for i in range(12):
+        M.m[i] = float(A.flat[i])
+    return M
+
+
+def mat3x3(R):
+    M = abi.Mat3x3()
+    A = R.astype(np.float32)
+    for i in range(9):
+        M.m[i] = float(A.flat[i])
+    return M
+
+
+def s8_pack(nx, ny):
+    """ImageSpaceNormalToU16 (BS/util.cuh:102-117)."""
+    def s8(v):
+        return (v * np.float32(127) + np.where(v > 0, np.float32(0.5), np.float32(-0.5))).astype(np.int8)
+    return s8(nx).view(np.uint8).astype(np.uint16) | (s8(ny).view(np.uint8).astype(np.uint16) << 8)
+
+
+def s10_pack(n):
+    """SurfelSetNormal (BS/util_nvcc_only.cuh:67-84): three signed 10-bit fields."""
+    def s10(v):
+        return (v * np.float32(511) + np.where(v > 0, np.float32(0.5), np.float32(-0.5))).astype(np.int16).astype(np.uint16).astype(np.uint32) & 0x3FF
+    return s10(n[..., 0]) | (s10(n[..., 1]) << 10) | (s10(n[..., 2]) << 20)
+
+
+class SyntheticStack:
+    """Host arrays of a synthetic keyframe stack + surfel SoA."""
+
+    def __init__(self, num_keyframes, width=640, height=480, cell=4, seed=0xBAD51A4,
+                 fx=525.0, fy=525.0, cx=320.0, cy=240.0, raw_to_float_depth=1.0 / 5000, baseline_fx=40.0,
+                 translation_range=0.25, rotation_range=0.12, plane_count=20, surfel_noise=0.002):
+        rng = np.random.default_rng(seed)
+        self.width, self.height, self.cell = width, height, cell
+        self.camera = abi.Camera4f(fx, fy, cx, cy, width, height)   # pixel-corner convention
+        self.raw_to_float_depth = np.float32(raw_to_float_depth)
+        self.baseline_fx = float(baseline_fx)
+        self.K = num_keyframes
+        planes = []
+        for _ in range(plane_count):
+            n = rng.uniform(-1, 1, 3)
+            n[2] = -1.0
+            planes.append(n / np.linalg.norm(n))
+        xs = (np.arange(width) - (cx - 0.5)) / fx
+        ys = (np.arange(height) - (cy - 0.5)) / fy
+        dxg, dyg = np.meshgrid(xs, ys)
+        dirs = np.stack([dxg, dyg, np.ones_like(dxg)], axis=-1)
+        self.depth = np.zeros((num_keyframes, height, width), np.uint16)
+        self.normals = np.zeros((num_keyframes, height, width), np.uint16)
+        self.radius = np.zeros((num_keyframes, height, width), np.uint16)
+        self.color = np.zeros((num_keyframes, height, width, 4), np.uint8)
+        self.R = []
+        self.t = []
+        surf = []
+        cw, ch = (width - 1) // cell + 1, (height - 1) // cell + 1
+        for k in range(num_keyframes):
+            xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
+            R, t = se3_exp(xi)
+            self.R.append(R)
+            self.t.append(t)
+            dg = dirs @ R.T
+            best = np.full((height, width), np.inf)
+            bestn = np.zeros((height, width, 3))
+            for n in planes:
+                denom = dg @ n
+                num = -(2.5 + t @ n)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tt = num / denom
+                tt = np.where((denom < 0) & (tt > 0.3), tt, np.inf)
+                upd = tt < best
+                best = np.where(upd, tt, best)
+                bestn = np.where(upd[..., None], n[None, None, :], bestn)
+            valid = np.isfinite(best) & (best < 6.0)
+            valid[0, :] = valid[-1, :] = False
+            valid[:, 0] = valid[:, -1] = False
+            d16 = np.where(valid, best / float(raw_to_float_depth) + 0.5, 65535).astype(np.uint32)
+            valid &= d16 < 32768
+            d16 = np.where(valid, d16, 65535).astype(np.uint16)
+            self.depth[k] = d16
+            n_cam = (bestn @ R).astype(np.float32)          # R^T n, rows
+            self.normals[k] = np.where(valid, s8_pack(n_cam[..., 0], n_cam[..., 1]), 0).astype(np.uint16)
+            z = (d16.astype(np.float32) * self.raw_to_float_depth)
+            r2 = np.where(valid, (z / np.float32(fx)) ** 2, 0).astype(np.float16)
+            self.radius[k] = r2.view(np.uint16)
+            pts = t[None, None, :] + dg * np.where(valid, best, 0.0)[..., None]
+            lum = (np.sin(7.0 * pts[..., 0] + 0.37) + np.sin(9.0 * pts[..., 1] + 0.5) + np.sin(11.0 * pts[..., 2] + 0.7)
+                   + 0.5 * np.sin(23.0 * (pts[..., 0] + pts[..., 1])) + 0.5 * np.cos(17.0 * (pts[..., 1] - pts[..., 2])))
+            lum = np.clip((lum + 4.0) / 8.0 * 255.0, 0, 255).astype(np.uint8)
+            self.color[k] = np.repeat(lum[:, :, None], 4, axis=2)
+            # cell-4 surfel creation without merge: first pixel of each cell, if valid
+            yy, xx = np.meshgrid(np.arange(ch) * cell + 1, np.arange(cw) * cell + 1, indexing="ij")
+            yy = np.minimum(yy, height - 2)
+            xx = np.minimum(xx, width - 2)
+            v = valid[yy, xx]
+            zc = z[yy, xx][v].astype(np.float32)
+            pcam = np.stack([zc * dxg[yy, xx][v].astype(np.float32), zc * dyg[yy, xx][v].astype(np.float32), zc], axis=-1)
+            pg = (pcam.astype(np.float64) @ R.T + t[None, :])
+            pg += bestn[yy, xx][v] * rng.uniform(-surfel_noise, surfel_noise, (pg.shape[0], 1))   # off-surface noise along the normal
+            s = np.zeros((abi.SURFEL_ATTRIBUTE_COUNT, pg.shape[0]), np.float32)
+            s[0:3] = pg.T.astype(np.float32)
+            s[3] = s10_pack(bestn[yy, xx][v].astype(np.float32)).view(np.float32)
+            s[4] = r2[yy, xx][v].astype(np.float32)
+            surf.append(s)
+        self.surfels = np.ascontiguousarray(np.concatenate(surf, axis=1))
+        self.surfels_size = self.surfels.shape[1]
+        self.cfactor = np.zeros(((height - 1) // cell + 1, (width - 1) // cell + 1), np.float32)
+
+    def pose(self, k, xi=None):
+        """(global_T_frame as SE3f, frame_T_global 3x4, global_R_frame) of keyframe k, optionally * exp(xi)."""
+        R, t = self.R[k], self.t[k]
+        if xi is not None:
+            dR, dt = se3_exp(xi)
+            t = t + R @ dt
+            R = R @ dR
+        Ri = R.T
+        ti = -R.T @ t
+        return make_se3f(R, t), mat3x4(Ri, ti), mat3x3(R)
+
+
+class DeviceStack:
+    """The stack in HBM (torch tensors) with POD views for the C ABI."""
+
+    def __init__(self, stack, device, surfel_range=None):
+        import torch
+        self.torch = torch
+        self.stack = stack
+        self.device = device
+        lo, hi = surfel_range if surfel_range is not None else (0, stack.surfels_size)
+        self.surfels = torch.from_numpy(np.ascontiguousarray(stack.surfels[:, lo:hi])).to(device)
+        self.surfels_size = hi - lo
+        self.active = torch.ones((1, max(1, self.surfels_size)), dtype=torch.uint8, device=device)
+        self.cfactor = torch.from_numpy(stack.cfactor).to(device)
+        self.depth = torch.from_numpy(stack.depth.view(np.int16)).to(device)
+        self.normals = torch.from_numpy(stack.normals.view(np.int16)).to(device)
+        self.radius = torch.from_numpy(stack.radius.view(np.int16)).to(device)
+        self.color = torch.from_numpy(stack.color).to(device)
+
+    @staticmethod
+    def buf(tensor):
+        return abi.Buffer2D(tensor.data_ptr(), tensor.shape[0], tensor.shape[1], tensor.stride(0) * tensor.element_size())
+
+    def depth_params(self):
+        dp = abi.DepthParams()
+        dp.cfactor_buffer = self.buf(self.cfactor)
+        dp.a = 0.0
+        dp.raw_to_float_depth = float(self.stack.raw_to_float_depth)
+        dp.baseline_fx = self.stack.baseline_fx
+        dp.sparse_surfel_cell_size = self.stack.cell
+        return dp
+
+    def keyframe_views(self, activation=abi.KF_ACTIVE):
+        K = self.stack.K
+        arr = (abi.KeyframeView * K)()
+        for k in range(K):
+            v = arr[k]
+            v.depth, v.normals = self.buf(self.depth[k]), self.buf(self.normals[k])
+            v.radius, v.color = self.buf(self.radius[k]), self.buf(self.color[k])
+            _, M, Rg = self.stack.pose(k)
+            v.frame_T_global, v.global_R_frame = M, Rg
+            v.activation = activation
+            v.id = k
+        return arr

@@ -158,6 +158,14 @@ int bslam_destroy(bslam_context* ctx);
 /* Texture filtering mode (BSLAM_TEX_*), default BSLAM_TEX_FIXED_POINT_1_8. */
 int bslam_set_texture_mode(bslam_context* ctx, int mode);
 
+/* Kernel timing for the roofline line of bench.py (the role of the reference's cudaEvent
+ * pairs, BS/direct_ba.h:513-532): while enabled, every launch of the dominant kernel of a
+ * call (the surfel x keyframe pass) is bracketed by HIP events on the launch stream.
+ * bslam_profile_read synchronises those events and returns launches and summed ms since
+ * the last enable/read. */
+int bslam_profile_enable(bslam_context* ctx, int enable);
+int bslam_profile_read(bslam_context* ctx, int32_t* launches, float* total_ms);
+
 /* ------------------------------------------------------------------------- */
 /* Pose optimisation                                                          */
 /* ------------------------------------------------------------------------- */
@@ -270,6 +278,27 @@ int bslam_debug_association(
     const bslam_keyframe_view* keyframe,
     uint32_t surfels_size, const bslam_buffer2d* surfels,
     uint32_t* out_pixel);
+
+/* Census for the roofline accounting of SURVEY.md 8(d): number of (surfel, keyframe) pairs
+ * that pass the z > 0 and image-bounds tests (pairs that do not stop after 12 bytes), and
+ * number of associated pairs.  HOST outputs, valid on return. */
+int bslam_debug_count_pairs(
+    bslam_context* ctx, void* stream,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    uint64_t* in_bounds_pairs, uint64_t* associated_pairs);
+
+/* Per-surfel residual probe for one keyframe (test / debugging aid): writes 8 floats
+ * per surfel to DEVICE out: [depth raw residual, depth weight, descriptor r1, w1, r2,
+ * w2, flags (bit0 associated, bit1 descriptor residuals valid), 0].  This is how the
+ * tests check "residuals within 1e-4 relative" surfel by surfel. */
+int bslam_debug_pose_residuals(
+    bslam_context* ctx, void* stream,
+    int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params, const bslam_keyframe_view* keyframe,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, float* out);
 
 /* ------------------------------------------------------------------------- */
 /* PCG (matrix-free Gauss-Newton step)                                        */

@@ -28,6 +28,15 @@ typedef struct { float x, y; } bso_f2;
 
 static inline bso_f3 bso_make3(float x, float y, float z) { bso_f3 r = {x, y, z}; return r; }
 
+/* float -> int as the GPU converts (CUDA cvt.rzi.s32.f32 and gfx950 v_cvt_i32_f32 both
+ * truncate, saturate out-of-range values and map NaN to 0; x86 would return INT_MIN). */
+static inline int bso_f2i(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)v;
+}
+
 /* ---- BS/cuda_util.cuh:52-107 ------------------------------------------------ */
 static inline float bso_sqlen(bso_f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }           /* :52 */
 static inline float bso_dot(bso_f3 a, bso_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   /* :57 */
@@ -110,7 +119,7 @@ static inline bso_depth_to_color bso_make_depth_to_color(const bslam_camera4f* d
 static inline int bso_depth_to_color_pxy(bso_f2 pxy, const bso_depth_to_color* d, bso_f2* out) {   /* BS/surfel_projection.cuh:196-207 */
   out->x = d->fx * pxy.x + d->cx;
   out->y = d->fy * pxy.y + d->cy;
-  return out->x >= 0 && out->y >= 0 && (int)(out->x) < d->width && (int)(out->y) < d->height;
+  return out->x >= 0 && out->y >= 0 && bso_f2i(out->x) < d->width && bso_f2i(out->y) < d->height;
 }
 
 /* ---- BS/util.cuh:46-53 ------------------------------------------------------- */
@@ -287,10 +296,13 @@ static inline void bso_raw_descriptor_residual(const bslam_buffer2d* color, int 
  * gradient at p from the four texel centres around it (tex2D at texel centres
  * returns the texel itself, for both filter models). */
 static inline void bso_point_gradient(const bslam_buffer2d* color, bso_f2 p, float* dx, float* dy) {
-  int ix = (int)fmaxf(0.f, p.x - 0.5f);
-  int iy = (int)fmaxf(0.f, p.y - 0.5f);
+  int ix = bso_f2i(fmaxf(0.f, p.x - 0.5f));
+  int iy = bso_f2i(fmaxf(0.f, p.y - 0.5f));
   float tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - ix));
   float ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - iy));
+  /* clamp before the +1 so that a saturated index cannot overflow (same texels as clamp addressing) */
+  if (ix > color->width - 1) ix = color->width - 1;
+  if (iy > color->height - 1) iy = color->height - 1;
   float top_left = bso_texel_w(color, ix, iy);
   float top_right = bso_texel_w(color, ix + 1, iy);
   float bottom_left = bso_texel_w(color, ix, iy + 1);
@@ -325,8 +337,8 @@ typedef struct {
 /* BS/util.cuh:67-99 */
 static inline int bso_project_surfel_to_image(int width, int height, const bslam_camera4f* cam, bso_f3 local, int* px, int* py, bso_f2* pxy) {
   *pxy = bso_project(cam->fx, cam->fy, cam->cx, cam->cy, local);
-  *px = (int)pxy->x;
-  *py = (int)pxy->y;
+  *px = bso_f2i(pxy->x);
+  *py = bso_f2i(pxy->y);
   if (pxy->x < 0 || pxy->y < 0 || *px >= width || *py >= height) return 0;
   return 1;
 }

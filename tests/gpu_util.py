@@ -1,0 +1,121 @@
+"""Helpers for the -m gpu parity tests: calls into the HIP library through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+import badslam_amd
+from badslam_amd import abi
+
+P = C.POINTER
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Hip:
+    """Thin call layer over include/badslam_hip.h for a tests.bso.DeviceScene."""
+
+    def __init__(self, dev_scene, ctx=None):
+        import torch
+        self.torch = torch
+        self.d = dev_scene
+        self.h = dev_scene.host
+        self.L = badslam_amd.lib()
+        self.ctx = ctx or badslam_amd.Context(0)
+        self.ctx.set_texture_mode(self.h.tex_mode)
+
+    def _common(self):
+        return self.d.depth_params(), self.d.surfel_buf()
+
+    def association(self, kf_index):
+        dp, sb = self._common()
+        v = self.d.keyframe_view(kf_index)
+        out = self.torch.empty(max(1, self.d.surfels_size), dtype=self.torch.int32, device=self.d.device)
+        badslam_amd.check(self.L.bslam_debug_association(self.ctx.handle, stream_ptr(), C.byref(self.h.depth_camera), C.byref(dp),
+                                                         C.byref(v), self.d.surfels_size, C.byref(sb), C.c_void_p(out.data_ptr())))
+        self.torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32)[:self.d.surfels_size]
+
+    def residual_probe(self, kf_index, use_depth=None, use_desc=None):
+        use_depth = self.h.use_depth_residuals if use_depth is None else use_depth
+        use_desc = self.h.use_descriptor_residuals if use_desc is None else use_desc
+        dp, sb = self._common()
+        v = self.d.keyframe_view(kf_index)
+        out = self.torch.zeros((max(1, self.d.surfels_size), 8), dtype=self.torch.float32, device=self.d.device)
+        badslam_amd.check(self.L.bslam_debug_pose_residuals(
+            self.ctx.handle, stream_ptr(), int(use_depth), int(use_desc), C.byref(self.h.color_camera), C.byref(self.h.depth_camera),
+            C.byref(dp), C.byref(v), self.d.surfels_size, C.byref(sb), C.c_void_p(out.data_ptr())))
+        self.torch.cuda.synchronize()
+        return out.cpu().numpy()[:self.d.surfels_size]
+
+    def accumulate_pose(self, kf_index, frame_T_global=None, use_depth=None, use_desc=None):
+        use_depth = self.h.use_depth_residuals if use_depth is None else use_depth
+        use_desc = self.h.use_descriptor_residuals if use_desc is None else use_desc
+        dp, sb = self._common()
+        v = self.d.keyframe_view(kf_index)
+        M = v.frame_T_global if frame_T_global is None else frame_T_global
+        H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+        cnt, cost = C.c_uint32(), C.c_float()
+        badslam_amd.check(self.L.bslam_accumulate_pose_estimation_coeffs(
+            self.ctx.handle, stream_ptr(), int(use_depth), int(use_desc), C.byref(self.h.color_camera), C.byref(self.h.depth_camera),
+            C.byref(dp), C.byref(v.depth), C.byref(v.normals), C.byref(v.color), C.byref(M), self.d.surfels_size, C.byref(sb),
+            1, C.byref(cnt), C.byref(cost), H.ctypes.data_as(P(C.c_float)), b.ctypes.data_as(P(C.c_float))))
+        return dict(H=H, b=b, count=cnt.value, cost=cost.value)
+
+    def accumulate_pose_batched(self, use_depth=None, use_desc=None, download=True):
+        use_depth = self.h.use_depth_residuals if use_depth is None else use_depth
+        use_desc = self.h.use_descriptor_residuals if use_desc is None else use_desc
+        dp, sb = self._common()
+        kfs = self.d.keyframe_views()
+        K = len(self.h.keyframes)
+        Hb = np.zeros((K, 27), np.float32)
+        counts = np.zeros(K, np.uint32)
+        badslam_amd.check(self.L.bslam_accumulate_pose_coeffs_batched(
+            self.ctx.handle, stream_ptr(), int(use_depth), int(use_desc), C.byref(self.h.color_camera), C.byref(self.h.depth_camera),
+            C.byref(dp), K, kfs, self.d.surfels_size, C.byref(sb),
+            Hb.ctypes.data_as(P(C.c_float)) if download else None, counts.ctypes.data_as(P(C.c_uint32)) if download else None))
+        return Hb, counts
+
+    def estimate_poses_batched(self, initial_poses, max_iterations=30, activations=None, allreduce=None):
+        dp, sb = self._common()
+        kfs = self.d.keyframe_views()
+        K = len(self.h.keyframes)
+        if activations is not None:
+            for k in range(K):
+                kfs[k].activation = activations[k]
+        poses = (abi.SE3f * K)()
+        for k in range(K):
+            C.memmove(C.byref(poses[k]), C.byref(initial_poses[k]), C.sizeof(abi.SE3f))
+        iters = (C.c_int32 * K)()
+        conv = (C.c_int32 * K)()
+        cb = allreduce if allreduce is not None else C.cast(None, abi.ALLREDUCE_FN)
+        badslam_amd.check(self.L.bslam_estimate_frame_poses_batched(
+            self.ctx.handle, stream_ptr(), int(self.h.use_depth_residuals), int(self.h.use_descriptor_residuals),
+            C.byref(self.h.color_camera), C.byref(self.h.depth_camera), C.byref(dp), K, kfs, self.d.surfels_size, C.byref(sb),
+            max_iterations, poses, iters, conv, cb, None))
+        return [poses[k] for k in range(K)], list(iters), list(conv)
+
+    def update_activation(self):
+        dp, sb = self._common()
+        ab, kfs = self.d.active_buf(), self.d.keyframe_views()
+        badslam_amd.check(self.L.bslam_update_surfel_activation(self.ctx.handle, stream_ptr(), C.byref(self.h.depth_camera), C.byref(dp),
+                                                                len(self.h.keyframes), kfs, self.d.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+
+    def update_normals(self):
+        dp, sb = self._common()
+        ab, kfs = self.d.active_buf(), self.d.keyframe_views()
+        badslam_amd.check(self.L.bslam_update_surfel_normals(self.ctx.handle, stream_ptr(), C.byref(self.h.depth_camera), C.byref(dp),
+                                                             len(self.h.keyframes), kfs, self.d.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+
+    def optimize_geometry_iteration(self):
+        dp, sb = self._common()
+        ab, kfs = self.d.active_buf(), self.d.keyframe_views()
+        badslam_amd.check(self.L.bslam_optimize_geometry_iteration(
+            self.ctx.handle, stream_ptr(), int(self.h.use_depth_residuals), int(self.h.use_descriptor_residuals),
+            C.byref(self.h.color_camera), C.byref(self.h.depth_camera), C.byref(dp), len(self.h.keyframes), kfs,
+            self.d.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()

@@ -1,0 +1,303 @@
+"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): association pixels / activation masks bit-exact; residuals,
+H/b coefficients and optimised poses within 1e-4 relative (tolerances written at each assert).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from badslam_amd import abi
+from tests import bso, scenes
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4   # north_star tolerance for floating-point outputs
+
+
+def rel_close(a, b, scale=None, rel=REL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = np.abs(b).max() if scale is None else scale
+    return np.abs(a - b).max() <= rel * max(scale, 1e-30)
+
+
+def pose_error(est, gt):
+    return bso.se3_log(bso.se3_mul(bso.se3_inverse(est), gt))
+
+
+@pytest.fixture(scope="module")
+def hip_mod():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    from tests import gpu_util
+    return gpu_util
+
+
+@pytest.fixture(scope="module")
+def geo(hip_mod, oracle):
+    scene, kf = scenes.pose_geometric_scene(seed=0)
+    return scene, kf, hip_mod.Hip(scene.to_device())
+
+
+@pytest.fixture(scope="module")
+def photo(hip_mod, oracle):
+    scene, kf, gt = scenes.pose_photometric_scene(seed=0)
+    return scene, kf, gt, hip_mod.Hip(scene.to_device())
+
+
+@pytest.fixture(scope="module")
+def multi(hip_mod, oracle):
+    scene = scenes.synthetic_scene(6, seed=3, use_depth_residuals=True, use_descriptor_residuals=True)
+    return scene, hip_mod.Hip(scene.to_device())
+
+
+def perturbed(kf, x):
+    """frame_T_global of global_T_frame * exp(x)."""
+    T = bso.se3_mul(kf.global_T_frame, bso.se3_exp(x))
+    return T, bso.se3_matrix3x4(bso.se3_inverse(T))
+
+
+# ----------------------------------------------------------------------------- association
+
+def test_association_bit_exact_single_keyframe(geo):
+    scene, kf, hip = geo
+    ref = scene.association(kf)
+    got = hip.association(0)
+    assert (ref != 0xFFFFFFFF).sum() > 100000
+    assert np.array_equal(ref, got)
+
+
+def test_association_bit_exact_multi_keyframe(multi):
+    scene, hip = multi
+    total = 0
+    for k, kf in enumerate(scene.keyframes):
+        ref = scene.association(kf)
+        got = hip.association(k)
+        total += int((ref != 0xFFFFFFFF).sum())
+        mism = int((ref != got).sum())
+        assert mism == 0, f"keyframe {k}: {mism} of {ref.size} association results differ"
+    assert total > scene.surfels_size   # surfels are seen by several keyframes
+
+
+# ----------------------------------------------------------------------------- residuals, H/b
+
+def test_depth_residuals_per_surfel(geo):
+    scene, kf, hip = geo
+    _, M = perturbed(kf, np.array([0.004, -0.003, 0.002, 0.001, -0.0005, 0.0008], np.float32))
+    # probe uses the keyframe's own pose; check that one, then H/b at the perturbed pose below
+    ref = scene.accumulate_pose(kf, per_surfel=True)["per_surfel"]
+    got = hip.residual_probe(0)
+    assert np.array_equal(ref[:, 6], got[:, 6])
+    assert rel_close(got[:, 0], ref[:, 0], scale=max(1.0, np.abs(ref[:, 0]).max()))
+    assert rel_close(got[:, 1], ref[:, 1], scale=1.0)
+
+
+def test_pose_coefficients_geometric(geo):
+    scene, kf, hip = geo
+    _, M = perturbed(kf, np.array([0.004, -0.003, 0.002, 0.001, -0.0005, 0.0008], np.float32))
+    ref = scene.accumulate_pose(kf, frame_T_global=M)
+    got = hip.accumulate_pose(0, frame_T_global=M)
+    assert got["count"] == ref["count"] and ref["count"] > 100000
+    # against the float64 sum of the oracle's fp32 terms, relative to the largest coefficient
+    assert rel_close(got["H"], ref["H64"])
+    assert rel_close(got["b"], ref["b64"])
+    assert rel_close(got["cost"], ref["cost"], scale=max(1.0, abs(ref["cost"])), rel=1e-3)   # fp32 serial sum of 1e5 terms on the oracle side
+
+
+def test_pose_coefficients_photometric(photo):
+    scene, kf, gt, hip = photo
+    _, M = perturbed(kf, np.array([0.0004, -0.0003, 0.0002, 0.0008, -0.0005, 0.0006], np.float32))
+    ref = scene.accumulate_pose(kf, frame_T_global=M, per_surfel=True)
+    got = hip.accumulate_pose(0, frame_T_global=M)
+    assert got["count"] == ref["count"] and ref["count"] > 250000
+    assert rel_close(got["H"], ref["H64"])
+    assert rel_close(got["b"], ref["b64"])
+
+
+def test_photometric_residuals_per_surfel(photo):
+    scene, kf, gt, hip = photo
+    ref = scene.accumulate_pose(kf, per_surfel=True)["per_surfel"]
+    got = hip.residual_probe(0)
+    assert np.array_equal(ref[:, 6], got[:, 6])
+    scale = max(1.0, np.abs(ref[:, [2, 4]]).max())
+    assert rel_close(got[:, 2], ref[:, 2], scale=scale)
+    assert rel_close(got[:, 4], ref[:, 4], scale=scale)
+    assert rel_close(got[:, 3], ref[:, 3], scale=1e-2)
+    assert rel_close(got[:, 5], ref[:, 5], scale=1e-2)
+
+
+def test_batched_coefficients_match_per_keyframe_oracle(multi):
+    scene, hip = multi
+    Hb, counts = hip.accumulate_pose_batched()
+    for k, kf in enumerate(scene.keyframes):
+        ref = scene.accumulate_pose(kf)
+        assert counts[k] == ref["count"]
+        assert rel_close(Hb[k, :21], ref["H64"]), k
+        assert rel_close(Hb[k, 21:], ref["b64"], scale=np.abs(ref["b64"]).max() + 1e-3 * np.abs(ref["H64"]).max()), k
+
+
+def test_batched_equals_single_keyframe_entry_point(multi):
+    """The reference-shaped per-keyframe entry point and the batched one run the same kernel:
+    deterministic sums, identical bits."""
+    scene, hip = multi
+    Hb, counts = hip.accumulate_pose_batched()
+    for k in range(len(scene.keyframes)):
+        one = hip.accumulate_pose(k)
+        assert np.array_equal(one["H"], Hb[k, :21]) and np.array_equal(one["b"], Hb[k, 21:])
+    Hb2, _ = hip.accumulate_pose_batched()
+    assert np.array_equal(Hb, Hb2), "sums must be reproducible run to run"
+
+
+# ----------------------------------------------------------------------------- pose Gauss-Newton
+
+def test_known_answer_pose_geometric_through_hip(geo):
+    """BS/test/test_pose_optimization_geometric_residual.cc:134-170 with the HIP path."""
+    scene, kf, hip = geo
+    gt = bso.se3_identity()
+    worst = 0.0
+    for off in scenes.offsets_13(0.005, 0.001):
+        init = bso.se3_mul(off, bso.se3_inverse(gt))
+        poses, iters, conv = hip.estimate_poses_batched([init])
+        ref, ref_iters, ref_conv = scene.estimate_frame_pose(kf, init)
+        err = pose_error(poses[0], gt)
+        worst = max(worst, float(np.abs(err).max()))
+        assert conv[0] == 1 and iters[0] <= 30
+        # optimised pose vs the oracle's: 1e-4 relative on the 7 SE3 numbers (|q| = 1, |t| ~ 5e-3..)
+        assert np.abs(bso.se3_to_np(poses[0]) - bso.se3_to_np(ref)).max() < 1e-6
+    assert worst < 1.1e-6, worst
+
+
+def test_known_answer_pose_photometric_through_hip(photo):
+    """BS/test/test_pose_optimization_photometric_residual.cc:141-177 with the HIP path."""
+    scene, kf, gt, hip = photo
+    worst = 0.0
+    for off in scenes.offsets_13(0.0005, 0.001)[:5]:
+        init = bso.se3_mul(gt, off)
+        poses, iters, conv = hip.estimate_poses_batched([init])
+        err = pose_error(poses[0], gt)
+        worst = max(worst, float(np.abs(err).max()))
+    assert worst < 8e-5, worst
+
+
+def test_batched_pose_estimation_matches_sequential_oracle(multi):
+    scene, hip = multi
+    rng = np.random.default_rng(5)
+    inits = []
+    for kf in scene.keyframes:
+        x = np.concatenate([rng.uniform(-0.004, 0.004, 3), rng.uniform(-0.001, 0.001, 3)]).astype(np.float32)
+        inits.append(bso.se3_mul(kf.global_T_frame, bso.se3_exp(x)))
+    poses, iters, conv = hip.estimate_poses_batched(inits)
+    for k, kf in enumerate(scene.keyframes):
+        ref, ref_iters, ref_conv = scene.estimate_frame_pose(kf, inits[k])
+        d = np.abs(bso.se3_to_np(poses[k]) - bso.se3_to_np(ref)).max()
+        assert d < 1e-4 * max(1.0, np.abs(bso.se3_to_np(ref)).max()), (k, d)
+        assert conv[k] == int(ref_conv)
+
+
+def test_inactive_keyframes_are_not_optimised(multi):
+    scene, hip = multi
+    inits = [bso.se3_mul(kf.global_T_frame, bso.se3_exp(np.array([0.003, 0, 0, 0, 0, 0], np.float32))) for kf in scene.keyframes]
+    acts = [abi.KF_INACTIVE if k % 2 else abi.KF_ACTIVE for k in range(len(inits))]
+    poses, iters, conv = hip.estimate_poses_batched(inits, activations=acts)
+    for k in range(len(inits)):
+        if acts[k] == abi.KF_INACTIVE:
+            assert iters[k] == 0 and np.array_equal(bso.se3_to_np(poses[k]), bso.se3_to_np(inits[k]))
+        else:
+            assert iters[k] > 0
+
+
+# ----------------------------------------------------------------------------- activation / geometry
+
+def fresh_multi(hip_mod, use_desc, seed=11, K=4):
+    scene = scenes.synthetic_scene(K, seed=seed, use_depth_residuals=True, use_descriptor_residuals=use_desc)
+    # move the surfels off their surfaces a little so that the geometry step has work to do
+    rng = np.random.default_rng(seed)
+    n = scene.surfels_size
+    scene.surfels[2, :n] += rng.uniform(-0.004, 0.004, n).astype(np.float32)
+    return scene, hip_mod.Hip(scene.to_device())
+
+
+def test_activation_mask_bit_exact(hip_mod, oracle):
+    scene, hip = fresh_multi(hip_mod, False)
+    scene.keyframes[1].activation = abi.KF_INACTIVE
+    scene.keyframes[2].activation = abi.KF_COVISIBLE_ACTIVE
+    scene.active[0, :scene.surfels_size] = np.random.default_rng(0).integers(0, 4, scene.surfels_size).astype(np.uint8)
+    hip.d.active.copy_(hip.torch.from_numpy(scene.active))
+    scene.update_activation()
+    hip.update_activation()
+    got = hip.d.active_np()
+    assert np.array_equal(got[0, :scene.surfels_size], scene.active[0, :scene.surfels_size])
+    assert 0 < (got[0, :scene.surfels_size] & 1).sum() < scene.surfels_size
+
+
+@pytest.mark.parametrize("use_desc", [False, True])
+def test_geometry_iteration_matches_oracle(hip_mod, oracle, use_desc):
+    scene, hip = fresh_multi(hip_mod, use_desc)
+    scene.keyframes[3].activation = abi.KF_INACTIVE
+    scene.active[0, ::7] = 0
+    hip.d.active.copy_(hip.torch.from_numpy(scene.active))
+    before = scene.surfels[:8, :scene.surfels_size].copy()
+    scene.optimize_geometry_iteration()
+    hip.optimize_geometry_iteration()
+    got = hip.d.surfels_np()[:8, :scene.surfels_size]
+    ref = scene.surfels[:8, :scene.surfels_size]
+    # normals are integers (3 x s10): bit-exact
+    assert np.array_equal(got[3].view(np.uint32), ref[3].view(np.uint32))
+    assert not np.array_equal(ref[:3], before[:3]), "the step must move surfels"
+    # positions / descriptors: same fp32 operations in the same order -> expect identical bits;
+    # the hard bar is 1e-4 relative
+    for row in (0, 1, 2, 6, 7):
+        assert rel_close(got[row], ref[row], scale=max(1.0, np.abs(ref[row]).max())), row
+    exact = sum(np.array_equal(got[r].view(np.uint32), ref[r].view(np.uint32)) for r in (0, 1, 2, 6, 7))
+    print("bit-exact rows:", exact, "of 5")
+    # inactive surfels untouched
+    assert np.array_equal(got[:, ::7].view(np.uint32), before[:, ::7].view(np.uint32))
+
+
+def test_update_normals_only(hip_mod, oracle):
+    scene, hip = fresh_multi(hip_mod, False, seed=12)
+    scene.update_normals()
+    hip.update_normals()
+    got = hip.d.surfels_np()[:8, :scene.surfels_size]
+    assert np.array_equal(got.view(np.uint32), scene.surfels[:8, :scene.surfels_size].view(np.uint32))
+
+
+# ----------------------------------------------------------------------------- edge cases
+
+def test_argument_checks(multi):
+    import badslam_amd
+    scene, hip = multi
+    dp, sb = hip.d.depth_params(), hip.d.surfel_buf()
+    v = hip.d.keyframe_view(0)
+    H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+    f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    L = badslam_amd.lib()
+    from tests.gpu_util import stream_ptr
+    # neither residual type: the reference CHECK()s (BS/kernel_opt_pose.cc:58)
+    rc = L.bslam_accumulate_pose_estimation_coeffs(hip.ctx.handle, stream_ptr(), 0, 0, C.byref(scene.color_camera), C.byref(scene.depth_camera),
+                                                   C.byref(dp), C.byref(v.depth), C.byref(v.normals), C.byref(v.color), C.byref(v.frame_T_global),
+                                                   scene.surfels_size, C.byref(sb), 0, None, None, f(H), f(b))
+    assert rc == -1
+    # surfels_size == 0: CHECK_GT (BS/kernel_opt_pose.cc:61)
+    rc = L.bslam_accumulate_pose_estimation_coeffs(hip.ctx.handle, stream_ptr(), 1, 0, C.byref(scene.color_camera), C.byref(scene.depth_camera),
+                                                   C.byref(dp), C.byref(v.depth), C.byref(v.normals), C.byref(v.color), C.byref(v.frame_T_global),
+                                                   0, C.byref(sb), 0, None, None, f(H), f(b))
+    assert rc == -1
+    # surfels_size larger than the buffer must be refused, not launched
+    rc = L.bslam_accumulate_pose_estimation_coeffs(hip.ctx.handle, stream_ptr(), 1, 0, C.byref(scene.color_camera), C.byref(scene.depth_camera),
+                                                   C.byref(dp), C.byref(v.depth), C.byref(v.normals), C.byref(v.color), C.byref(v.frame_T_global),
+                                                   scene.max_surfels + 1, C.byref(sb), 0, None, None, f(H), f(b))
+    assert rc == -1
+
+
+def test_ragged_surfel_count(hip_mod, oracle):
+    """surfels_size not a multiple of the tile: the tail threads must not contribute."""
+    scene = scenes.synthetic_scene(2, seed=21, use_depth_residuals=True, use_descriptor_residuals=False)
+    scene.surfels_size = scene.surfels_size - 333
+    hip = hip_mod.Hip(scene.to_device())
+    for k, kf in enumerate(scene.keyframes):
+        ref = scene.accumulate_pose(kf)
+        got = hip.accumulate_pose(k)
+        assert got["count"] == ref["count"]
+        assert rel_close(got["H"], ref["H64"])
