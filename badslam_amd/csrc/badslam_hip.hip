@@ -387,6 +387,9 @@ int bslam_estimate_frame_poses_batched(
   PoseState* d_states = (PoseState*)ctx->pose_state.ptr;
   int* d_active = (int*)ctx->misc.ptr;
   int* h_active = (int*)((uint8_t*)ctx->staging2.ptr + state_bytes);
+  hipLaunchKernelGGL(pose_init_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream, keyframe_count,
+                     (const PoseState*)d_states, (KfDev*)ctx->kf_table.ptr);
+  BSLAM_HIP_TRY(hipGetLastError());
 
   for (int it = 0; it < max_iterations; ++it) {
     BSLAM_HIP_TRY(hipMemsetAsync(d_active, 0, sizeof(int), stream));

@@ -25,7 +25,7 @@ __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y 
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {                                                     // BS/cuda_util.cuh:78
   return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
-__device__ __forceinline__ float norm3(f3 v) { return __fsqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z); }  // BS/cuda_util.cuh:85
+__device__ __forceinline__ float norm3(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }  // BS/cuda_util.cuh:85
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 scale3(float m, f3 b) { return mk3(m * b.x, m * b.y, m * b.z); }
@@ -100,7 +100,7 @@ __device__ __forceinline__ f3 u16_to_image_space_normal(uint32_t value) {
   r.x = (float)(int8_t)(value & 0xff) * (1.0f / 127);
   r.y = (float)(int8_t)((value >> 8) & 0xff) * (1.0f / 127);
   r.z = 1 - r.x * r.x - r.y * r.y;
-  r.z = -__fsqrt_rn((r.z > 0.f) ? r.z : 0.f);
+  r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
   return r;
 }
 
@@ -192,10 +192,10 @@ __device__ __forceinline__ float tex_w(const uint8_t* color, uint32_t pitch, int
 // BS/cost_function.cuh:115-136
 __device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_squared, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
   f3 t1 = cross(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
-  t1 = scale3(__fsqrt_rn(radius_squared / fmaxf(1e-12f, sqlen(t1))), scale3(2.0f, t1));
+  t1 = scale3(sqrtf(radius_squared / fmaxf(1e-12f, sqlen(t1))), scale3(2.0f, t1));
   *t1_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t1)));
   f3 t2 = cross(gn, t1);
-  t2 = scale3(__fsqrt_rn(radius_squared / fmaxf(1e-12f, sqlen(t2))), scale3(2.0f, t2));
+  t2 = scale3(sqrtf(radius_squared / fmaxf(1e-12f, sqlen(t2))), scale3(2.0f, t2));
   *t2_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t2)));
 }
 

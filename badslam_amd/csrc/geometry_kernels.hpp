@@ -228,12 +228,12 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     }
     float H00 = A0, H01 = A1, H02 = A2, H11 = A3, H12 = 0.f, H22 = A5;
     H00 += 1e-6f; H11 += 1e-6f; H22 += 1e-6f;
-    H00 = __fsqrt_rn(H00);
+    H00 = sqrtf(H00);
     H01 = H01 / H00;
-    H11 = __fsqrt_rn(H11 - H01 * H01);
+    H11 = sqrtf(H11 - H01 * H01);
     H02 = H02 / H00;
     H12 = (H12 - H02 * H01) / H11;
-    H22 = __fsqrt_rn(H22 - H02 * H02 - H12 * H12);
+    H22 = sqrtf(H22 - H02 * H02 - H12 * H12);
     const float y0 = A6 / H00;
     const float y1 = (A7 - H01 * y0) / H11;
     const float y2 = (A8 - H02 * y0 - H12 * y1) / H22;

@@ -220,7 +220,7 @@ __device__ inline void se3_exp(const float* a, Quat* q_out, f3* t_out) {
   const float kEps = 1e-5f;
   const f3 omega = mk3(a[3], a[4], a[5]);
   const float theta_sq = sqlen(omega);
-  const float theta = __fsqrt_rn(theta_sq);
+  const float theta = sqrtf(theta_sq);
   const float half_theta = 0.5f * theta;
   float imag_factor, real_factor;
   if (theta < kEps) {
@@ -313,6 +313,15 @@ __device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* 
   for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
   for (int k = n - 1; k >= 0; --k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
   for (int i = 0; i < n; ++i) x[i] = (float)y[i];
+}
+
+// frame_T_global_estimate = global_T_frame_estimate.inverse() for every keyframe's start pose
+// (BS/direct_ba_alternating.cc:140).
+__global__ void pose_init_kernel(int kf_count, const PoseState* __restrict__ states, KfDev* __restrict__ kfs) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= kf_count) return;
+  const PoseState st = states[k];
+  se3_inverse_matrix(Quat{st.q[0], st.q[1], st.q[2], st.q[3]}, mk3(st.t[0], st.t[1], st.t[2]), kfs[k].frame_T_global.m);
 }
 
 // One Gauss-Newton update per keyframe (BS/direct_ba_alternating.cc:206-233).
