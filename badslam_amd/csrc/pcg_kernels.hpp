@@ -1,2 +1,627 @@
-// pcg_kernels.hpp -- placeholder until the PCG kernels land (see pcg_abi.inc).
+// pcg_kernels.hpp -- matrix-free preconditioned conjugate gradient kernels (gfx950).
+//
+// Replaces BS/kernel_pcg.cu.  The reference launches PCGInit / PCGStep1 once per keyframe over
+// all surfels, with 13-29 block reductions + float atomics per residual and read-modify-write
+// of the per-surfel entries of r, M, g on every launch.  Here one launch covers all keyframes:
+//   * a thread keeps kPcgR surfels and their r/M (or p/g) entries in registers and walks the
+//     keyframe table in list order, so per-surfel sums are formed in the reference's order and
+//     written once;
+//   * per-keyframe pose entries are reduced wave -> LDS -> one row per (tile, keyframe) and
+//     summed over tiles by a second kernel in a fixed order (deterministic);
+//   * the global intrinsics entries and alpha_d are accumulated per thread over the whole loop
+//     and reduced once per block; only the per-cell cfactor entries use float atomics (as the
+//     reference does, BS/kernel_pcg.cu:319).
 #pragma once
+
+#include "device_math.hpp"
+#include "pose_kernels.hpp"
+
+namespace bslam {
+
+constexpr float kDiagEpsilon = 1e-8f;   // BS/kernel_pcg.cu:44
+constexpr float kAPriorWeight = 10.f;   // BS/kernel_pcg.cu:48
+constexpr uint32_t kInvalidUnknown = 0xffffffffu;
+
+constexpr int kPcgThreads = 256;
+constexpr int kPcgR = 2;
+constexpr int kPcgTile = kPcgThreads * kPcgR;
+constexpr int kPcgPoseRow = 12;    // init: r[6], M[6];  step1: g[6] (+6 unused)
+constexpr int kPcgGlobRow = 20;    // init: depth intr r[5], M[5], colour r[4], M[4]; step1: alpha_d, g depth[5], g colour[4]
+
+struct PcgParams {
+  uint32_t unknown_count, surfel_start, depth_intr_start, a_index, color_intr_start;
+  int gauge_kf;
+  int optimize_poses, optimize_geometry, optimize_depth_intr, optimize_color_intr;
+  int per_surfel;   // 1 (geometry only) or 3 (with descriptors)
+  float* r; float* M; float* delta; float* g; float* p;
+  float* alpha_n; float* alpha_d; float* beta_n;
+};
+
+__device__ __forceinline__ uint32_t kf_pose_unknown_index(int gauge, int id) {   // BS/direct_ba_pcg.cc:329-337
+  if (id == gauge) return kInvalidUnknown;
+  return (uint32_t)(6 * (id < gauge ? id : id - 1));
+}
+
+// Block-wide sum of `n` per-thread values (n <= 20) into out[0..n) by thread 0..n-1; all threads call.
+template <int N>
+__device__ __forceinline__ void block_reduce_rows(float* vals, float (*red)[32], float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = wave_sum(vals[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[wave][i] = vals[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < N) out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+struct DepthIntrinsicsTerms {
+  bool valid;
+  float d[5];           // fx_inv, fy_inv, cx_inv, cy_inv, a
+  float cf_jac;         // Jacobian wrt. the cfactor cell
+  uint32_t cf_index;    // unknown index of that cell
+};
+
+// BS/kernel_pcg.cu:258-322 / 721-772
+__device__ __forceinline__ DepthIntrinsicsTerms depth_intrinsics_terms(const CamConsts& c, const KfDev& kf, const Proj& p, f3 gn, float inv_stddev, uint32_t d0) {
+  DepthIntrinsicsTerms t;
+  const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
+  const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
+  const uint32_t measured = *(const uint16_t*)(kf.depth + (size_t)p.py * kf.depth_pitch + 2 * (size_t)p.px);
+  const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)measured);
+  const float exp_inv_depth = expf(-c.a * raw_inv_depth);
+  const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+  t.valid = !(fabsf(corrected_inv_depth) < 1e-4f);
+  const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
+  const float dt = dot(mk3(nx, ny, 1), p.n_local);
+  const float jac_base = inv_stddev * dt * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
+  const float* m = kf.frame_T_global.m;
+  t.d[2] = inv_stddev * p.depth * dot(gn, mk3(m[0], m[1], m[2]));
+  t.d[3] = inv_stddev * p.depth * dot(gn, mk3(m[4], m[5], m[6]));
+  t.d[0] = (float)p.px * t.d[2];
+  t.d[1] = (float)p.py * t.d[3];
+  t.d[4] = cfactor * raw_inv_depth * jac_base;
+  t.cf_jac = -jac_base;
+  t.cf_index = d0 + 5 + (uint32_t)sparse_px + (uint32_t)sparse_py * (uint32_t)c.cfactor_width;
+  return t;
+}
+
+struct DescTerms {
+  float r1, r2, w1, w2;
+  float gx1, gy1, gx2, gy2;   // image gradients already multiplied by the colour focal lengths
+};
+
+__device__ __forceinline__ DescTerms descriptor_terms(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, float radius_squared, float d1, float d2, f2 color_pxy) {
+  DescTerms t;
+  f2 t1, t2;
+  tangent_projections(gp, gn, radius_squared, kf.frame_T_global, c, &t1, &t2);
+  raw_descriptor_residual(kf, c, color_pxy, t1, t2, d1, d2, &t.r1, &t.r2);
+  descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
+  t.gx1 *= c.cfx; t.gx2 *= c.cfx;
+  t.gy1 *= c.cfy; t.gy2 *= c.cfy;
+  t.w1 = desc_weight(t.r1);
+  t.w2 = desc_weight(t.r2);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCGInit for all keyframes (BS/kernel_pcg.cu:179-513, BS/direct_ba_pcg.cc:339-365)
+// ---------------------------------------------------------------------------------------------
+template <bool kDepth, bool kDesc, bool kIntr>
+__global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRows s, PcgParams P,
+    float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  const int tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[2][4][32];
+  __shared__ float redg[4][32];
+
+  f3 gp[kPcgR], gn[kPcgR];
+  bool valid[kPcgR];
+  uint32_t idx[kPcgR];
+  float r2[kPcgR], d1[kPcgR], d2[kPcgR];
+  float ar[kPcgR][3], aM[kPcgR][3];
+#pragma unroll
+  for (int r = 0; r < kPcgR; ++r) {
+    const uint32_t i = (uint32_t)tile * kPcgTile + r * kPcgThreads + threadIdx.x;
+    valid[r] = i < s.size;
+    idx[r] = valid[r] ? i : 0;
+    gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
+    gn[r] = unpack_normal(s.normal[idx[r]]);
+    if (kDesc) { r2[r] = s.radius_squared[idx[r]]; d1[r] = s.d1[idx[r]]; d2[r] = s.d2[idx[r]]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ar[r][j] = 0.f; aM[r][j] = 0.f; }
+  }
+  float glob[kPcgGlobRow];
+#pragma unroll
+  for (int i = 0; i < kPcgGlobRow; ++i) glob[i] = 0.f;
+
+  int parity = 0;
+  for (int k = 0; k < kf_count; ++k) {
+    const KfDev& kf = kfs[k];
+    const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
+    const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
+    float pose[kPcgPoseRow];
+#pragma unroll
+    for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = 0.f;
+
+#pragma unroll
+    for (int r = 0; r < kPcgR; ++r) {
+      Proj p;
+      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      bool visible = true;
+      const f3 rn = p.n_local;
+      if (kDepth) {
+        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
+        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float weight = depth_weight(raw);
+        if (P.optimize_geometry) {                               // :217-221
+          const float jp = -inv_stddev;
+          ar[r][0] -= jp * weight * raw;
+          aM[r][0] += jp * weight * jp;
+        }
+        if (opt_pose) {                                          // :224-255
+          const float J[6] = {inv_stddev * rn.x, inv_stddev * rn.y, inv_stddev * rn.z,
+                              inv_stddev * (-rn.y * lu.z + rn.z * lu.y), inv_stddev * (rn.x * lu.z - rn.z * lu.x),
+                              inv_stddev * (-rn.x * lu.y + rn.y * lu.x)};
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const float wj = weight * J[j];
+            pose[j] += -1 * wj * raw;
+            pose[6 + j] += J[j] * wj;
+          }
+        }
+        if (kIntr && P.optimize_depth_intr) {                    // :258-322
+          const DepthIntrinsicsTerms t = depth_intrinsics_terms(c, kf, p, gn[r], inv_stddev, P.depth_intr_start);
+          if (t.valid) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              const float wj = weight * t.d[j];
+              glob[j] += -1 * wj * raw;
+              glob[5 + j] += t.d[j] * wj;
+            }
+            const float wj = weight * t.cf_jac;
+            atomicAdd(&P.r[t.cf_index], -1 * wj * raw);
+            atomicAdd(&P.M[t.cf_index], t.cf_jac * wj);
+          } else {
+            visible = false;                                      // :272 (also disables the descriptor part)
+          }
+        }
+      }
+      if (kDesc) {                                               // :330-511
+        f2 color_pxy;
+        visible = visible && depth_to_color_pxy(c, p.pxy, &color_pxy);
+        if (!visible) continue;
+        const DescTerms t = descriptor_terms(c, kf, gp[r], gn[r], r2[r], d1[r], d2[r], color_pxy);
+        const f3 ls = p.local;
+        if (P.optimize_geometry) {                               // :364-399
+          const float term1 = -(rn.x * ls.z - rn.z * ls.x);
+          const float term2 = -(rn.y * ls.z - rn.z * ls.y);
+          const float term3 = 1.f / (ls.z * ls.z);
+          const float jp1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
+          const float jp2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
+          ar[r][0] -= jp1 * t.w1 * t.r1 + jp2 * t.w2 * t.r2;
+          aM[r][0] += jp1 * t.w1 * jp1 + jp2 * t.w2 * jp2;
+          const float j11 = -1, j12 = 0, j21 = 0, j22 = -1;
+          ar[r][1] -= j11 * t.w1 * t.r1 + j12 * t.w2 * t.r2;
+          aM[r][1] += j11 * t.w1 * j11 + j12 * t.w2 * j12;
+          ar[r][2] -= j21 * t.w1 * t.r1 + j22 * t.w2 * t.r2;
+          aM[r][2] += j21 * t.w1 * j21 + j22 * t.w2 * j22;
+        }
+        if (opt_pose) {                                          // :402-459
+          float J1[6], J2[6];
+          descriptor_pose_jacobian(t.gx1, t.gy1, ls, J1);
+          descriptor_pose_jacobian(t.gx2, t.gy2, ls, J2);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const float wj1 = t.w1 * J1[j], wj2 = t.w2 * J2[j];
+            pose[j] += -1 * wj1 * t.r1 + -1 * wj2 * t.r2;
+            pose[6 + j] += J1[j] * wj1 + J2[j] * wj2;
+          }
+        }
+        if (kIntr && P.optimize_color_intr) {                    // :462-509
+          const float gx_1 = t.gx1 / c.cfx, gy_1 = t.gy1 / c.cfy, gx_2 = t.gx2 / c.cfx, gy_2 = t.gy2 / c.cfy;
+          const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
+          const float Jc1[4] = {gx_1 * nx, gy_1 * ny, gx_1, gy_1};
+          const float Jc2[4] = {gx_2 * nx, gy_2 * ny, gx_2, gy_2};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float wj1 = t.w1 * Jc1[j], wj2 = t.w2 * Jc2[j];
+            glob[10 + j] += -1 * wj1 * t.r1 + -1 * wj2 * t.r2;
+            glob[14 + j] += Jc1[j] * wj1 + Jc2[j] * wj2;
+          }
+        }
+      }
+    }
+
+    if (opt_pose) {   // uniform
+#pragma unroll
+      for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = wave_sum(pose[i]);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < kPcgPoseRow; ++i) red[parity][wave][i] = pose[i];
+      }
+      __syncthreads();
+      if (threadIdx.x < kPcgPoseRow)
+        partial_pose[((size_t)tile * kf_count + k) * kPcgPoseRow + threadIdx.x] =
+            ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x];
+      parity ^= 1;
+    }
+  }
+
+  if (P.optimize_geometry) {
+#pragma unroll
+    for (int r = 0; r < kPcgR; ++r) {
+      if (!valid[r]) continue;
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      P.r[base] = ar[r][0];
+      P.M[base] = aM[r][0];
+      if (kDesc) {
+        P.r[base + 1] = ar[r][1]; P.M[base + 1] = aM[r][1];
+        P.r[base + 2] = ar[r][2]; P.M[base + 2] = aM[r][2];
+      }
+    }
+  }
+  if (kIntr) block_reduce_rows<kPcgGlobRow>(glob, redg, partial_glob + (size_t)tile * kPcgGlobRow);
+}
+
+// Sums the per-tile pose rows of one keyframe and stores them at its unknown indices.
+// mode 0: init (r, M get rows 0-5 / 6-11); mode 1: step1 (g gets rows 0-5).
+__global__ __launch_bounds__(64) void pcg_pose_reduce_kernel(const float* __restrict__ partial_pose, int tiles, int kf_count,
+                                                            const KfDev* __restrict__ kfs, PcgParams P, int mode) {
+  const int k = blockIdx.x;
+  const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kfs[k].id);
+  if (kf_idx == kInvalidUnknown) return;
+  const int col = threadIdx.x;
+  if (col >= kPcgPoseRow) return;
+  float v = 0.f;
+  for (int t = 0; t < tiles; ++t) v += partial_pose[((size_t)t * kf_count + k) * kPcgPoseRow + col];
+  if (mode == 0) {
+    if (col < 6) P.r[kf_idx + col] = v; else P.M[kf_idx + col - 6] = v;
+  } else {
+    if (col < 6) P.g[kf_idx + col] = v;
+  }
+}
+
+// Sums the per-tile global rows.  mode 0: init -> r, M of the intrinsics; mode 1: step1 -> alpha_d and g.
+// Adds to the destination (cfactor-independent entries were zeroed by the caller's memset).
+__global__ __launch_bounds__(64) void pcg_glob_reduce_kernel(const float* __restrict__ partial_glob, int tiles, PcgParams P, int mode,
+                                                            int kf_count, const float* __restrict__ eps_term) {
+  const int col = threadIdx.x;
+  if (col >= kPcgGlobRow) return;
+  float v = 0.f;
+  for (int t = 0; t < tiles; ++t) v += partial_glob[(size_t)t * kPcgGlobRow + col];
+  if (mode == 0) {
+    if (P.optimize_depth_intr) {
+      if (col < 5) P.r[P.depth_intr_start + col] += v;
+      else if (col < 10) P.M[P.depth_intr_start + col - 5] += v;
+    }
+    if (P.optimize_color_intr) {
+      if (col >= 10 && col < 14) P.r[P.color_intr_start + col - 10] += v;
+      else if (col >= 14 && col < 18) P.M[P.color_intr_start + col - 14] += v;
+    }
+  } else {
+    if (col == 0) {
+      // alpha_d = sum over pairs + (epsilon term added once per keyframe: quirk Q7, BS/kernel_pcg.cu:1102-1113)
+      float a = v;
+      const float e = *eps_term;
+      for (int k = 0; k < kf_count; ++k) a += e;
+      *P.alpha_d = a;
+    } else if (col < 6) {
+      if (P.optimize_depth_intr) P.g[P.depth_intr_start + col - 1] += v;
+    } else if (col < 10) {
+      if (P.optimize_color_intr) P.g[P.color_intr_start + col - 6] += v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCGStep1 for all keyframes (BS/kernel_pcg.cu:645-1025)
+// ---------------------------------------------------------------------------------------------
+template <bool kDepth, bool kDesc, bool kIntr>
+__global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRows s, PcgParams P,
+    float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  const int tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[2][4][32];
+  __shared__ float redg[4][32];
+
+  f3 gp[kPcgR], gn[kPcgR];
+  bool valid[kPcgR];
+  uint32_t idx[kPcgR];
+  float r2[kPcgR], d1[kPcgR], d2[kPcgR];
+  float ps[kPcgR][3], ag[kPcgR][3];
+#pragma unroll
+  for (int r = 0; r < kPcgR; ++r) {
+    const uint32_t i = (uint32_t)tile * kPcgTile + r * kPcgThreads + threadIdx.x;
+    valid[r] = i < s.size;
+    idx[r] = valid[r] ? i : 0;
+    gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
+    gn[r] = unpack_normal(s.normal[idx[r]]);
+    if (kDesc) { r2[r] = s.radius_squared[idx[r]]; d1[r] = s.d1[idx[r]]; d2[r] = s.d2[idx[r]]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ps[r][j] = 0.f; ag[r][j] = 0.f; }
+    if (P.optimize_geometry) {
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      ps[r][0] = P.p[base];
+      if (kDesc) { ps[r][1] = P.p[base + 1]; ps[r][2] = P.p[base + 2]; }
+    }
+  }
+  float glob[kPcgGlobRow];
+#pragma unroll
+  for (int i = 0; i < kPcgGlobRow; ++i) glob[i] = 0.f;
+  float pdi[5] = {0, 0, 0, 0, 0}, pci[4] = {0, 0, 0, 0};
+  if (kIntr && P.optimize_depth_intr) for (int j = 0; j < 5; ++j) pdi[j] = P.p[P.depth_intr_start + j];
+  if (kIntr && P.optimize_color_intr) for (int j = 0; j < 4; ++j) pci[j] = P.p[P.color_intr_start + j];
+
+  int parity = 0;
+  for (int k = 0; k < kf_count; ++k) {
+    const KfDev& kf = kfs[k];
+    const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
+    const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
+    float pp[6] = {0, 0, 0, 0, 0, 0};
+    if (opt_pose) for (int j = 0; j < 6; ++j) pp[j] = P.p[kf_idx + j];
+    float pose[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pose[i] = 0.f;
+
+#pragma unroll
+    for (int r = 0; r < kPcgR; ++r) {
+      Proj p;
+      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      bool visible = true;
+      const f3 rn = p.n_local;
+      if (kDepth) {
+        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
+        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float weight = depth_weight(raw);
+        float sum = 0;
+        float gj = 0;
+        float J[6] = {0, 0, 0, 0, 0, 0};
+        if (P.optimize_geometry) { gj = -inv_stddev; sum += gj * ps[r][0]; }
+        if (opt_pose) {
+          J[0] = inv_stddev * rn.x;                              sum += J[0] * pp[0];
+          J[1] = inv_stddev * rn.y;                              sum += J[1] * pp[1];
+          J[2] = inv_stddev * rn.z;                              sum += J[2] * pp[2];
+          J[3] = inv_stddev * (-rn.y * lu.z + rn.z * lu.y);      sum += J[3] * pp[3];
+          J[4] = inv_stddev * (rn.x * lu.z - rn.z * lu.x);       sum += J[4] * pp[4];
+          J[5] = inv_stddev * (-rn.x * lu.y + rn.y * lu.x);      sum += J[5] * pp[5];
+        }
+        DepthIntrinsicsTerms t;
+        t.valid = false;
+        if (kIntr && P.optimize_depth_intr) {
+          t = depth_intrinsics_terms(c, kf, p, gn[r], inv_stddev, P.depth_intr_start);
+          if (t.valid) {
+            sum += t.d[2] * pdi[2];
+            sum += t.d[3] * pdi[3];
+            sum += t.d[0] * pdi[0];
+            sum += t.d[1] * pdi[1];
+            sum += t.d[4] * pdi[4];
+            sum += t.cf_jac * P.p[t.cf_index];
+          }
+        }
+        glob[0] += sum * weight * sum;
+        sum *= weight;
+        if (P.optimize_geometry) ag[r][0] += gj * sum;
+        if (opt_pose) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) pose[j] += J[j] * sum;
+        }
+        if (kIntr && P.optimize_depth_intr && t.valid) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) glob[1 + j] += t.d[j] * sum;
+          atomicAdd(&P.g[t.cf_index], t.cf_jac * sum);
+        }
+      }
+      if (kDesc) {
+        f2 color_pxy;
+        visible = visible && depth_to_color_pxy(c, p.pxy, &color_pxy);
+        if (!visible) continue;
+        const DescTerms t = descriptor_terms(c, kf, gp[r], gn[r], r2[r], d1[r], d2[r], color_pxy);
+        const f3 ls = p.local;
+        float sum_1 = 0, sum_2 = 0, gj1 = 0, gj2 = 0;
+        float J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};
+        float Jc1[4] = {0, 0, 0, 0}, Jc2[4] = {0, 0, 0, 0};
+        if (P.optimize_geometry) {
+          const float term1 = -(rn.x * ls.z - rn.z * ls.x);
+          const float term2 = -(rn.y * ls.z - rn.z * ls.y);
+          const float term3 = 1.f / (ls.z * ls.z);
+          gj1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
+          gj2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
+          sum_1 += gj1 * ps[r][0];
+          sum_2 += gj2 * ps[r][0];
+          sum_1 += -1.f * ps[r][1];
+          sum_2 += -1.f * ps[r][2];
+        }
+        if (opt_pose) {
+          descriptor_pose_jacobian(t.gx1, t.gy1, ls, J1);
+          descriptor_pose_jacobian(t.gx2, t.gy2, ls, J2);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) { sum_1 += J1[j] * pp[j]; sum_2 += J2[j] * pp[j]; }
+        }
+        if (kIntr && P.optimize_color_intr) {
+          const float gx_1 = t.gx1 / c.cfx, gy_1 = t.gy1 / c.cfy, gx_2 = t.gx2 / c.cfx, gy_2 = t.gy2 / c.cfy;
+          const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
+          Jc1[0] = gx_1 * nx; Jc1[1] = gy_1 * ny; Jc1[2] = gx_1; Jc1[3] = gy_1;
+          Jc2[0] = gx_2 * nx; Jc2[1] = gy_2 * ny; Jc2[2] = gx_2; Jc2[3] = gy_2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sum_1 += Jc1[j] * pci[j]; sum_2 += Jc2[j] * pci[j]; }
+        }
+        glob[0] += sum_1 * t.w1 * sum_1 + sum_2 * t.w2 * sum_2;
+        sum_1 *= t.w1;
+        sum_2 *= t.w2;
+        if (P.optimize_geometry) {
+          ag[r][0] += gj1 * sum_1 + gj2 * sum_2;
+          ag[r][1] += -1.f * sum_1 + 0.f * sum_2;
+          ag[r][2] += 0.f * sum_1 + -1.f * sum_2;
+        }
+        if (opt_pose) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) pose[j] += J1[j] * sum_1 + J2[j] * sum_2;
+        }
+        if (kIntr && P.optimize_color_intr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) glob[6 + j] += Jc1[j] * sum_1 + Jc2[j] * sum_2;
+        }
+      }
+    }
+
+    if (opt_pose) {   // uniform
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pose[i] = wave_sum(pose[i]);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) red[parity][wave][i] = pose[i];
+      }
+      __syncthreads();
+      if (threadIdx.x < kPcgPoseRow)
+        partial_pose[((size_t)tile * kf_count + k) * kPcgPoseRow + threadIdx.x] = (threadIdx.x < 6)
+            ? ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x] : 0.f;
+      parity ^= 1;
+    }
+  }
+
+  if (P.optimize_geometry) {
+#pragma unroll
+    for (int r = 0; r < kPcgR; ++r) {
+      if (!valid[r]) continue;
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      P.g[base] = ag[r][0];
+      if (kDesc) { P.g[base + 1] = ag[r][1]; P.g[base + 2] = ag[r][2]; }
+    }
+  }
+  block_reduce_rows<10>(glob, redg, partial_glob + (size_t)tile * kPcgGlobRow);
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector kernels over the unknowns with deterministic dot products
+// ---------------------------------------------------------------------------------------------
+constexpr int kVecThreads = 256;
+constexpr int kVecPerThread = 4;
+constexpr int kVecTile = kVecThreads * kVecPerThread;
+
+__device__ __forceinline__ float diag_extra(uint32_t i, uint32_t a_index) {
+  return kDiagEpsilon + ((i == a_index) ? (kAPriorWeight * kAPriorWeight) : 0);
+}
+
+__device__ __forceinline__ void block_sum_to(float v, float* out) {
+  __shared__ float sm[kVecThreads / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+// PCGInit2CUDAKernel BS/kernel_pcg.cu:564-606: partial[b] = sum r*p
+__global__ __launch_bounds__(kVecThreads) void pcg_init2_kernel(PcgParams P, float a, float* __restrict__ partial) {
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kVecPerThread; ++j) {
+    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
+    if (i < P.unknown_count) {
+      P.g[i] = 0;
+      const float r_value = P.r[i] + ((i == P.a_index) ? (-kAPriorWeight * kAPriorWeight * a) : 0);
+      const float p_value = r_value / (P.M[i] + kDiagEpsilon + ((i == P.a_index) ? (kAPriorWeight * kAPriorWeight) : 0));
+      P.p[i] = p_value;
+      P.delta[i] = 0;
+      acc += r_value * p_value;
+    }
+  }
+  block_sum_to(acc, &partial[blockIdx.x]);
+}
+
+// AddAlphaDEpsilonTermsCUDAKernel BS/kernel_pcg.cu:1027-1048: partial[b] = sum (eps [+100]) p^2
+__global__ __launch_bounds__(kVecThreads) void pcg_eps_kernel(PcgParams P, float* __restrict__ partial) {
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kVecPerThread; ++j) {
+    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
+    if (i < P.unknown_count) { const float p = P.p[i]; acc += diag_extra(i, P.a_index) * p * p; }
+  }
+  block_sum_to(acc, &partial[blockIdx.x]);
+}
+
+// PCGStep2CUDAKernel BS/kernel_pcg.cu:1116-1170: partial[b] = sum z*r
+__global__ __launch_bounds__(kVecThreads) void pcg_step2_kernel(PcgParams P, float* __restrict__ partial) {
+  const float ad = *P.alpha_d;
+  const float alpha = (ad >= 1e-35f) ? (*P.alpha_n / ad) : 0;
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < kVecPerThread; ++j) {
+    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
+    if (i < P.unknown_count) {
+      const float p_value = P.p[i];
+      P.delta[i] += alpha * p_value;
+      float r_value = P.r[i];
+      r_value -= alpha * (P.g[i] + diag_extra(i, P.a_index) * p_value);
+      P.r[i] = r_value;
+      const float z_value = r_value / (P.M[i] + kDiagEpsilon + ((i == P.a_index) ? (kAPriorWeight * kAPriorWeight) : 0));
+      P.g[i] = z_value;
+      acc += z_value * r_value;
+    }
+  }
+  block_sum_to(acc, &partial[blockIdx.x]);
+}
+
+// PCGStep3CUDAKernel BS/kernel_pcg.cu:1211-1230
+__global__ __launch_bounds__(kVecThreads) void pcg_step3_kernel(PcgParams P) {
+  const float an = *P.alpha_n;
+  const float beta = (an >= 1e-35f) ? (*P.beta_n / an) : 0;
+#pragma unroll
+  for (int j = 0; j < kVecPerThread; ++j) {
+    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
+    if (i < P.unknown_count) P.p[i] = P.g[i] + beta * P.p[i];
+  }
+}
+
+// Sums `n` block partials in index order into *out (one block).
+__global__ __launch_bounds__(256) void pcg_final_sum_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float sm[256];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// UpdateSurfelsFromPCGDeltaCUDAKernel BS/kernel_pcg.cu:1305-1333
+template <bool kDesc>
+__global__ __launch_bounds__(256) void pcg_update_surfels_kernel(float* x, float* y, float* z, const uint32_t* normal, float* d1, float* d2,
+                                                                 uint32_t size, uint32_t s0, const float* __restrict__ delta) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size) return;
+  const float t = delta[s0 + (kDesc ? 3 : 1) * i];
+  if (t != 0) {
+    const f3 n = unpack_normal(normal[i]);
+    x[i] = x[i] + t * n.x;
+    y[i] = y[i] + t * n.y;
+    z[i] = z[i] + t * n.z;
+  }
+  if (kDesc) {
+    float a = d1[i];
+    a += delta[s0 + 3 * i + 1];
+    d1[i] = fmaxf(-180.f, fminf(180.f, a));
+    float b = d2[i];
+    b += delta[s0 + 3 * i + 2];
+    d2[i] = fmaxf(-180.f, fminf(180.f, b));
+  }
+}
+
+// UpdateCFactorsFromPCGDeltaCUDAKernel BS/kernel_pcg.cu:1361-1372
+__global__ __launch_bounds__(256) void pcg_update_cfactors_kernel(uint8_t* cf, uint32_t pitch, int w, int h, uint32_t start, const float* __restrict__ delta) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)(w * h)) return;
+  const uint32_t yy = i / (uint32_t)w, xx = i - yy * (uint32_t)w;
+  float* p = (float*)(cf + (size_t)yy * pitch) + xx;
+  *p += delta[start + i];
+}
+
+}  // namespace bslam

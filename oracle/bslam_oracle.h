@@ -116,6 +116,7 @@ void bso_pcg_step1(const bslam_pcg_layout* layout,
                    int keyframe_count, const bslam_keyframe_view* keyframes,
                    uint32_t surfels_size, const bslam_buffer2d* surfels,
                    const bslam_pcg_vectors* v, int clear_g, int tex_mode);
+double bso_pcg_last_alpha_d64(void);  /* float64 sum of the alpha_d terms of the last bso_pcg_step1 */
 void bso_pcg_step2(const bslam_pcg_layout* layout, const bslam_pcg_vectors* v, float* beta_n_host);
 void bso_pcg_step3(const bslam_pcg_layout* layout, const bslam_pcg_vectors* v);
 void bso_update_surfels_from_pcg_delta(uint32_t surfels_size, const bslam_buffer2d* surfels,

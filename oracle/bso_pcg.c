@@ -14,6 +14,12 @@
 #define K_A_PRIOR_WEIGHT 10.f  /* BS/kernel_pcg.cu:48 */
 #define INVALID_INDEX 0xffffffffu
 
+/* float64 sum of the same fp32 alpha_d terms of the last bso_pcg_step1 call: the fp32 serial sum
+ * over ~1e5..1e7 terms carries ~1e-4 relative rounding error itself, so parity of the (tree-summed)
+ * device value is judged against this one. */
+static double g_alpha_d64;
+double bso_pcg_last_alpha_d64(void) { return g_alpha_d64; }
+
 /* get_kf_pose_unknown_index BS/direct_ba_pcg.cc:329-337 */
 static uint32_t kf_pose_unknown_index(const bslam_pcg_layout* l, int keyframe_id) {
   if (keyframe_id == l->gauge_keyframe_id) return INVALID_INDEX;
@@ -252,6 +258,7 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
         }
       }
       *v->alpha_d += sum * weight * sum;
+      g_alpha_d64 += (double)(sum * weight * sum);
       sum *= weight;
       if (l->optimize_geometry) v->g[l->surfel_unknown_start_index + per_surfel * i + 0] += geometry_jacobian * sum;
       if (optimize_poses) for (int k = 0; k < 6; ++k) v->g[kf_idx + k] += pose_jacobian[k] * sum;
@@ -339,6 +346,7 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
         cj2[3] = g_y_2; sum_2 += cj2[3] * p;
       }
       *v->alpha_d += sum_1 * w1 * sum_1 + sum_2 * w2 * sum_2;
+      g_alpha_d64 += (double)(sum_1 * w1 * sum_1 + sum_2 * w2 * sum_2);
       sum_1 *= w1;
       sum_2 *= w2;
       if (l->optimize_geometry) {
@@ -359,6 +367,7 @@ void bso_pcg_step1(const bslam_pcg_layout* layout,
                    uint32_t surfels_size, const bslam_buffer2d* surfels,
                    const bslam_pcg_vectors* v, int clear_g, int tex_mode) {
   *v->alpha_d = 0.f;                                               /* BS/direct_ba_pcg.cc:383 */
+  g_alpha_d64 = 0.0;
   if (clear_g) for (uint32_t i = 0; i < layout->unknown_count; ++i) v->g[i] = 0.f;   /* :393 */
   if (surfels_size == 0) return;
   pcg_cams c;
@@ -374,6 +383,7 @@ void bso_pcg_step1(const bslam_pcg_layout* layout,
       acc += (K_DIAG_EPSILON + ((i == layout->a_unknown_index) ? (K_A_PRIOR_WEIGHT * K_A_PRIOR_WEIGHT) : 0)) * p * p;
     }
     *v->alpha_d += acc;
+    g_alpha_d64 += (double)acc;
   }
 }
 

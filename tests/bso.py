@@ -62,6 +62,7 @@ def lib():
         "bso_pcg_init": (None, [P(abi.PCGLayout), _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(abi.PCGVectors), C.c_int]),
         "bso_pcg_init2": (None, [P(abi.PCGLayout), C.c_float, P(abi.PCGVectors)]),
         "bso_pcg_step1": (None, [P(abi.PCGLayout), _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(abi.PCGVectors), C.c_int, C.c_int]),
+        "bso_pcg_last_alpha_d64": (C.c_double, []),
         "bso_pcg_step2": (None, [P(abi.PCGLayout), P(abi.PCGVectors), f32p]),
         "bso_pcg_step3": (None, [P(abi.PCGLayout), P(abi.PCGVectors)]),
         "bso_update_surfels_from_pcg_delta": (None, [C.c_uint32, _BUF, C.c_int, C.c_uint32, f32p]),
@@ -354,3 +355,88 @@ class DeviceScene:
 
     def active_np(self):
         return self.active.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- PCG helpers
+
+def pcg_layout(scene, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False,
+               optimize_color_intrinsics=False, gauge_keyframe_id=0):
+    """Unknown ordering of BS/direct_ba_pcg.cc:270-306."""
+    K = len(scene.keyframes)
+    cur = 0
+    if optimize_poses:
+        cur += 6 * (K - 1)
+    surfel_start = abi.INVALID_INDEX
+    if optimize_geometry:
+        surfel_start = cur
+        cur += (3 if scene.use_descriptor_residuals else 1) * scene.surfels_size
+    depth_start = a_index = abi.INVALID_INDEX
+    if optimize_depth_intrinsics:
+        depth_start = cur
+        cur += 4 + 1 + scene.cfactor.shape[0] * scene.cfactor.shape[1]
+        a_index = depth_start + 4
+    color_start = abi.INVALID_INDEX
+    if optimize_color_intrinsics:
+        color_start = cur
+        cur += 4
+    return abi.PCGLayout(cur, surfel_start, depth_start, a_index, color_start, gauge_keyframe_id,
+                         int(optimize_poses), int(optimize_geometry), int(optimize_depth_intrinsics),
+                         int(optimize_color_intrinsics), int(scene.use_depth_residuals), int(scene.use_descriptor_residuals))
+
+
+class HostPCG:
+    """PCG vectors in host memory + the oracle's PCG steps (BS/kernel_pcg.cu restated)."""
+    NAMES = ("r", "M", "delta", "g", "p")
+
+    def __init__(self, scene, layout):
+        self.scene, self.layout = scene, layout
+        n = max(1, layout.unknown_count)
+        for nm in self.NAMES:
+            setattr(self, nm, np.zeros(n, np.float32))
+        self.scalars = np.zeros(3, np.float32)   # alpha_n, alpha_d, beta_n
+        self.an, self.bn = 0, 2
+
+    def vectors(self):
+        v = abi.PCGVectors()
+        for nm in self.NAMES:
+            setattr(v, nm, getattr(self, nm).ctypes.data)
+        base = self.scalars.ctypes.data
+        v.alpha_n, v.alpha_d, v.beta_n = base + 4 * self.an, base + 4, base + 4 * self.bn
+        return v
+
+    def swap_alpha_beta(self):   # std::swap(pcg_alpha_n_, pcg_beta_n_) BS/direct_ba_pcg.cc:390
+        self.an, self.bn = self.bn, self.an
+
+    def _args(self):
+        s = self.scene
+        return (C.byref(self.layout), C.byref(s.color_camera), C.byref(s.depth_camera))
+
+    def init(self):
+        s = self.scene
+        dp, sb, kfs, v = s.depth_params(), s.surfel_buf(), s.keyframe_views(), self.vectors()
+        lib().bso_pcg_init(*self._args(), C.byref(dp), len(s.keyframes), kfs, s.surfels_size, C.byref(sb), C.byref(v), s.tex_mode)
+
+    def init2(self):
+        v = self.vectors()
+        lib().bso_pcg_init2(C.byref(self.layout), self.scene.a, C.byref(v))
+
+    def step1(self, clear_g):
+        s = self.scene
+        dp, sb, kfs, v = s.depth_params(), s.surfel_buf(), s.keyframe_views(), self.vectors()
+        lib().bso_pcg_step1(*self._args(), C.byref(dp), len(s.keyframes), kfs, s.surfels_size, C.byref(sb), C.byref(v), int(clear_g), s.tex_mode)
+
+    def step2(self):
+        v = self.vectors()
+        out = C.c_float()
+        lib().bso_pcg_step2(C.byref(self.layout), C.byref(v), C.byref(out))
+        return out.value
+
+    def step3(self):
+        v = self.vectors()
+        lib().bso_pcg_step3(C.byref(self.layout), C.byref(v))
+
+    def apply_delta_to_surfels(self):
+        s = self.scene
+        sb = s.surfel_buf()
+        lib().bso_update_surfels_from_pcg_delta(s.surfels_size, C.byref(sb), int(s.use_descriptor_residuals),
+                                                self.layout.surfel_unknown_start_index, fptr(self.delta))

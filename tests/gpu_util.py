@@ -119,3 +119,84 @@ class Hip:
             C.byref(self.h.color_camera), C.byref(self.h.depth_camera), C.byref(dp), len(self.h.keyframes), kfs,
             self.d.surfels_size, C.byref(sb), C.byref(ab)))
         self.torch.cuda.synchronize()
+
+
+class HipPCG:
+    """PCG vectors in HBM + the HIP PCG entry points."""
+    NAMES = ("r", "M", "delta", "g", "p")
+
+    def __init__(self, hip, layout):
+        import torch
+        self.hip, self.layout = hip, layout
+        n = max(1, layout.unknown_count)
+        dev = hip.d.device
+        # garbage-fill: the entry points must not rely on zero-initialised vectors
+        for nm in self.NAMES:
+            setattr(self, nm, torch.full((n,), 123.0, dtype=torch.float32, device=dev))
+        self.scalars = torch.full((3,), 7.0, dtype=torch.float32, device=dev)
+        self.an, self.bn = 0, 2
+
+    def vectors(self):
+        v = abi.PCGVectors()
+        for nm in self.NAMES:
+            setattr(v, nm, getattr(self, nm).data_ptr())
+        base = self.scalars.data_ptr()
+        v.alpha_n, v.alpha_d, v.beta_n = base + 4 * self.an, base + 4, base + 4 * self.bn
+        return v
+
+    def swap_alpha_beta(self):
+        self.an, self.bn = self.bn, self.an
+
+    def get(self, name):
+        return getattr(self, name).cpu().numpy()
+
+    def load_from(self, host_pcg):
+        """Copies the oracle-side vectors and scalars into HBM (so one kernel is tested at a time)."""
+        torch = self.hip.torch
+        for nm in self.NAMES:
+            getattr(self, nm).copy_(torch.from_numpy(getattr(host_pcg, nm)))
+        self.scalars.copy_(torch.from_numpy(host_pcg.scalars))
+        self.an, self.bn = host_pcg.an, host_pcg.bn
+
+    def scalar(self, which):
+        s = self.scalars.cpu().numpy()
+        return float(s[{"alpha_n": self.an, "alpha_d": 1, "beta_n": self.bn}[which]])
+
+    def _surf_args(self):
+        h, d = self.hip.h, self.hip.d
+        return h, d.depth_params(), d.surfel_buf(), d.keyframe_views()
+
+    def init(self):
+        h, dp, sb, kfs = self._surf_args()
+        v = self.vectors()
+        badslam_amd.check(self.hip.L.bslam_pcg_init(self.hip.ctx.handle, stream_ptr(), C.byref(self.layout), C.byref(h.color_camera),
+                                                    C.byref(h.depth_camera), C.byref(dp), len(h.keyframes), kfs, self.hip.d.surfels_size,
+                                                    C.byref(sb), C.byref(v)))
+
+    def init2(self):
+        v = self.vectors()
+        badslam_amd.check(self.hip.L.bslam_pcg_init2(self.hip.ctx.handle, stream_ptr(), C.byref(self.layout), self.hip.h.a, C.byref(v)))
+
+    def step1(self, clear_g):
+        h, dp, sb, kfs = self._surf_args()
+        v = self.vectors()
+        badslam_amd.check(self.hip.L.bslam_pcg_step1(self.hip.ctx.handle, stream_ptr(), C.byref(self.layout), C.byref(h.color_camera),
+                                                     C.byref(h.depth_camera), C.byref(dp), len(h.keyframes), kfs, self.hip.d.surfels_size,
+                                                     C.byref(sb), C.byref(v), int(clear_g)))
+
+    def step2(self):
+        v = self.vectors()
+        out = C.c_float()
+        badslam_amd.check(self.hip.L.bslam_pcg_step2(self.hip.ctx.handle, stream_ptr(), C.byref(self.layout), C.byref(v), C.byref(out)))
+        return out.value
+
+    def step3(self):
+        v = self.vectors()
+        badslam_amd.check(self.hip.L.bslam_pcg_step3(self.hip.ctx.handle, stream_ptr(), C.byref(self.layout), C.byref(v)))
+
+    def apply_delta_to_surfels(self):
+        sb = self.hip.d.surfel_buf()
+        badslam_amd.check(self.hip.L.bslam_update_surfels_from_pcg_delta(
+            self.hip.ctx.handle, stream_ptr(), self.hip.d.surfels_size, C.byref(sb), int(self.hip.h.use_descriptor_residuals),
+            self.layout.surfel_unknown_start_index, C.c_void_p(self.delta.data_ptr())))
+        self.hip.torch.cuda.synchronize()
