@@ -18,11 +18,23 @@ class BadSlamError(RuntimeError):
     pass
 
 
+def preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same soname as /opt/rocm's).  If our
+    libraries are loaded first they pull in /opt/rocm's copy and torch then loads a second HIP
+    runtime, which finds no GPU.  Importing torch first makes the bundled copy the one and only
+    runtime of the process; without torch installed there is nothing to do."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     """Loads libbadslam_hip.so and applies the signatures of include/badslam_hip.h."""
     global _lib
     if _lib is not None:
         return _lib
+    preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise BadSlamError(
             f"{LIB_PATH} is missing: build it with `python -m badslam_amd.build` "

@@ -26,13 +26,32 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HOST = os.path.join(HERE, "host")
+HOST_SO = os.path.join(HERE, "libbadslam_host.so")
+# host-only C++ (DirectBA loops); no device code, links the kernel library by $ORIGIN rpath
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-D__HIP_PLATFORM_AMD__",
+              "-I/opt/rocm/include", "-L" + HERE, "-lbadslam_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def needs_host_build():
+    if not os.path.exists(HOST_SO):
+        return True
+    t = os.path.getmtime(HOST_SO)
+    deps = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(HERE, "..", "include", "badslam_hip.h"), SO]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return SO
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", SO]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    if force or needs_build():
+        cmd = [HIPCC] + FLAGS + sources() + ["-o", SO]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    if force or needs_host_build():
+        cmd = ["g++"] + [os.path.join(HOST, f) for f in ("direct_ba.cpp", "c_api.cpp")] + HOST_FLAGS + ["-o", HOST_SO]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
     return SO
 
 

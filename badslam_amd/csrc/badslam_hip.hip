@@ -312,7 +312,7 @@ int bslam_accumulate_pose_estimation_coeffs(
   std::memcpy(b, out + 21, 6 * sizeof(float));
   if (debug) {
     if (residual_sum) *residual_sum = out[kRowCost];
-    if (residual_count) std::memcpy(residual_count, out + kRowCount, sizeof(uint32_t));
+    if (residual_count) *residual_count = (uint32_t)out[kRowCount] + ((uint32_t)out[kRowCount + 1] << 16);
   }
   return BSLAM_OK;
 }
@@ -344,7 +344,7 @@ int bslam_accumulate_pose_coeffs_batched(
     const float* out = (const float*)ctx->staging2.ptr;
     for (int k = 0; k < keyframe_count; ++k) {
       if (Hb) std::memcpy(Hb + 27 * (size_t)k, out + (size_t)k * kRow, 27 * sizeof(float));
-      if (counts) std::memcpy(&counts[k], out + (size_t)k * kRow + kRowCount, sizeof(uint32_t));
+      if (counts) counts[k] = (uint32_t)out[(size_t)k * kRow + kRowCount] + ((uint32_t)out[(size_t)k * kRow + kRowCount + 1] << 16);
     }
   }
   return BSLAM_OK;

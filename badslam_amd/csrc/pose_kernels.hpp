@@ -174,10 +174,13 @@ __global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x < kRow) {
     if (col == kRowCount) {
+      // the residual count leaves this kernel as two exactly representable floats (low / high 16 bits)
+      // so that the row can go through a float all-reduce (sum) across GPUs unchanged in meaning
       uint32_t total = 0;
       for (int i = 0; i < 8; ++i) total += __float_as_uint(sm[i][col]);
-      coeffs[(size_t)k * kRow + col] = __uint_as_float(total);
-    } else {
+      coeffs[(size_t)k * kRow + kRowCount] = (float)(total & 0xffffu);
+      coeffs[(size_t)k * kRow + kRowCount + 1] = (float)(total >> 16);
+    } else if (col != kRowCount + 1) {
       float total = 0.f;
       for (int i = 0; i < 8; ++i) total += sm[i][col];
       coeffs[(size_t)k * kRow + col] = total;

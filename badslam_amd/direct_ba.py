@@ -1,0 +1,184 @@
+"""ctypes binding of the C++ host class bslam_host::DirectBA (badslam_amd/host/), the MI355X
+counterpart of the reference's DirectBA (BS/direct_ba.h).  Method names follow the reference."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "libbadslam_host.so")
+_host = None
+
+
+class DirectBAError(RuntimeError):
+    pass
+
+
+def host_lib():
+    global _host
+    if _host is not None:
+        return _host
+    from . import preload_torch_hip_runtime
+    preload_torch_hip_runtime()
+    if not os.path.exists(HOST_LIB_PATH):
+        raise DirectBAError(f"{HOST_LIB_PATH} is missing: build it with `python -m badslam_amd.build`")
+    L = C.CDLL(HOST_LIB_PATH)
+    f32p, u16p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint16), C.POINTER(C.c_uint8)
+    L.bsh_last_error.restype = C.c_char_p
+    L.bsh_create.restype = C.c_void_p
+    L.bsh_create.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                             f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.bsh_destroy.argtypes = [C.c_void_p]
+    L.bsh_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, u16p, u16p, u16p, u8p, f32p]
+    L.bsh_set_surfels.argtypes = [C.c_void_p, C.c_void_p, f32p, C.c_size_t, C.c_uint32]
+    L.bsh_get_surfels.argtypes = [C.c_void_p, C.c_void_p, f32p, C.c_size_t, C.c_int]
+    L.bsh_get_active_surfels.argtypes = [C.c_void_p, C.c_void_p, u8p]
+    L.bsh_surfels_size.restype = C.c_uint32
+    L.bsh_surfels_size.argtypes = [C.c_void_p]
+    L.bsh_keyframe_count.argtypes = [C.c_void_p]
+    L.bsh_get_keyframe_pose.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.bsh_set_keyframe_pose.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.bsh_get_keyframe_activation.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_set_keyframe_activation.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.bsh_keyframe_covisibility.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.bsh_upload_keyframe_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
+    L.bsh_upload_keyframe_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
+    L.bsh_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.bsh_set_allreduce.argtypes = [C.c_void_p, abi.ALLREDUCE_FN, C.c_void_p]
+    L.bsh_estimate_frame_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p]
+    L.bsh_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bsh_get_intrinsics.argtypes = [C.c_void_p, f32p, f32p, f32p]
+    _host = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def pose7(se3f):
+    return np.array(list(se3f.q) + list(se3f.t), np.float32)
+
+
+def se3f_from7(p):
+    T = abi.SE3f()
+    for i in range(4):
+        T.q[i] = float(p[i])
+    for i in range(3):
+        T.t[i] = float(p[4 + i])
+    return T
+
+
+class DirectBA:
+    """Drives bslam_host::DirectBA.  Constructor arguments are those of BS/direct_ba.h:73-88."""
+
+    def __init__(self, max_surfel_count, raw_to_float_depth, baseline_fx, sparse_surfel_cell_size, surfel_merge_dist_factor,
+                 min_observation_count_while_bootstrapping_1, min_observation_count_while_bootstrapping_2, min_observation_count,
+                 color_camera, depth_camera, pyramid_level_for_color, use_depth_residuals, use_descriptor_residuals, device=0, stream=None):
+        self.L = host_lib()
+        cc = np.array([color_camera.fx, color_camera.fy, color_camera.cx, color_camera.cy], np.float32)
+        dc = np.array([depth_camera.fx, depth_camera.fy, depth_camera.cx, depth_camera.cy], np.float32)
+        self._ba = self.L.bsh_create(max_surfel_count, raw_to_float_depth, baseline_fx, sparse_surfel_cell_size, surfel_merge_dist_factor,
+                                     min_observation_count_while_bootstrapping_1, min_observation_count_while_bootstrapping_2,
+                                     min_observation_count, _f(cc), color_camera.width, color_camera.height, _f(dc), depth_camera.width,
+                                     depth_camera.height, pyramid_level_for_color, int(use_depth_residuals), int(use_descriptor_residuals), device)
+        if not self._ba:
+            raise DirectBAError(self.L.bsh_last_error().decode())
+        self.stream = C.c_void_p(stream) if stream else C.c_void_p(None)
+
+    def _check(self, rc):
+        if rc < 0:
+            raise DirectBAError(self.L.bsh_last_error().decode())
+        return rc
+
+    def close(self):
+        if self._ba:
+            self.L.bsh_destroy(self._ba)
+            self._ba = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def AddKeyframe(self, frame_index, min_depth, max_depth, depth, normals, radius, color, global_T_frame):
+        p = pose7(global_T_frame)
+        u16 = lambda a: np.ascontiguousarray(a, np.uint16).ctypes.data_as(C.POINTER(C.c_uint16))
+        col = np.ascontiguousarray(color, np.uint8)
+        return self._check(self.L.bsh_add_keyframe(self._ba, self.stream, frame_index, min_depth, max_depth, u16(depth), u16(normals), u16(radius),
+                                                   col.ctypes.data_as(C.POINTER(C.c_uint8)), _f(p)))
+
+    def SetSurfels(self, rows, count):
+        rows = np.ascontiguousarray(rows, np.float32)
+        self._check(self.L.bsh_set_surfels(self._ba, self.stream, _f(rows), rows.strides[0], count))
+
+    def GetSurfels(self, nrows=8):
+        n = self.surfels_size()
+        out = np.zeros((nrows, max(1, n)), np.float32)
+        self._check(self.L.bsh_get_surfels(self._ba, self.stream, _f(out), out.strides[0], nrows))
+        return out[:, :n]
+
+    def GetActiveSurfels(self):
+        n = self.surfels_size()
+        out = np.zeros(max(1, n), np.uint8)
+        self._check(self.L.bsh_get_active_surfels(self._ba, self.stream, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out[:n]
+
+    def surfels_size(self):
+        return self.L.bsh_surfels_size(self._ba)
+
+    def keyframe_pose(self, kf_id):
+        out = np.zeros(7, np.float32)
+        self._check(self.L.bsh_get_keyframe_pose(self._ba, kf_id, _f(out)))
+        return se3f_from7(out)
+
+    def set_keyframe_pose(self, kf_id, T):
+        self._check(self.L.bsh_set_keyframe_pose(self._ba, kf_id, _f(pose7(T))))
+
+    def keyframe_activation(self, kf_id):
+        return self.L.bsh_get_keyframe_activation(self._ba, kf_id)
+
+    def set_keyframe_activation(self, kf_id, act):
+        self._check(self.L.bsh_set_keyframe_activation(self._ba, kf_id, act))
+
+    def keyframe_covisibility(self, kf_id):
+        buf = (C.c_int * 4096)()
+        n = self.L.bsh_keyframe_covisibility(self._ba, kf_id, buf, 4096)
+        return list(buf[:n])
+
+    def upload_keyframe_depth(self, kf_id, depth):
+        d = np.ascontiguousarray(depth, np.uint16)
+        self._check(self.L.bsh_upload_keyframe_depth(self._ba, self.stream, kf_id, d.ctypes.data_as(C.POINTER(C.c_uint16))))
+
+    def upload_keyframe_normals(self, kf_id, normals):
+        d = np.ascontiguousarray(normals, np.uint16)
+        self._check(self.L.bsh_upload_keyframe_normals(self._ba, self.stream, kf_id, d.ctypes.data_as(C.POINTER(C.c_uint16))))
+
+    def set_options(self, batched_pose_optimization=True, pcg_gauge_keyframe=-1, texture_mode=abi.TEX_FIXED_POINT_1_8):
+        self._check(self.L.bsh_set_options(self._ba, int(batched_pose_optimization), pcg_gauge_keyframe, texture_mode))
+
+    def set_allreduce(self, callback):
+        self._check(self.L.bsh_set_allreduce(self._ba, callback, None))
+
+    def EstimateFramePose(self, kf_id, global_T_frame_initial_estimate):
+        out = np.zeros(7, np.float32)
+        self._check(self.L.bsh_estimate_frame_pose(self._ba, self.stream, kf_id, _f(pose7(global_T_frame_initial_estimate)), _f(out)))
+        return se3f_from7(out)
+
+    def BundleAdjustment(self, optimize_depth_intrinsics, optimize_color_intrinsics, do_surfel_updates, optimize_poses, optimize_geometry,
+                         min_iterations, max_iterations, use_pcg, active_keyframe_window_start, active_keyframe_window_end,
+                         increase_ba_iteration_count, pcg_max_inner_iterations=30):
+        it, conv = C.c_int(), C.c_int()
+        self._check(self.L.bsh_bundle_adjustment(self._ba, self.stream, int(optimize_depth_intrinsics), int(optimize_color_intrinsics),
+                                                 int(do_surfel_updates), int(optimize_poses), int(optimize_geometry), min_iterations,
+                                                 max_iterations, int(use_pcg), active_keyframe_window_start, active_keyframe_window_end,
+                                                 int(increase_ba_iteration_count), pcg_max_inner_iterations, C.byref(it), C.byref(conv)))
+        return it.value, bool(conv.value)
+
+    def intrinsics(self):
+        c, d, a = np.zeros(4, np.float32), np.zeros(4, np.float32), C.c_float()
+        self._check(self.L.bsh_get_intrinsics(self._ba, _f(c), _f(d), C.byref(a)))
+        return c, d, a.value

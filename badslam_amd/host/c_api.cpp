@@ -1,0 +1,145 @@
+// c_api.cpp -- flat C API over bslam_host::DirectBA so that the Python tests (ctypes) and other
+// FFIs can drive the C++ host class.  Exceptions never cross the boundary: they are turned into a
+// negative return code + bsh_last_error().
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "direct_ba.hpp"
+
+using namespace bslam_host;
+
+static thread_local std::string g_err;
+
+#define BSH_TRY(body)                         \
+  try { body; return 0; }                     \
+  catch (const std::exception& e) { g_err = e.what(); return -1; } \
+  catch (...) { g_err = "unknown exception"; return -1; }
+
+static SE3f pose_from7(const float* p) { bslam_se3f q; std::memcpy(q.q, p, 16); std::memcpy(q.t, p + 4, 12); return SE3f::FromPod(q); }
+static void pose_to7(const SE3f& T, float* p) { const bslam_se3f q = T.ToPod(); std::memcpy(p, q.q, 16); std::memcpy(p + 4, q.t, 12); }
+
+extern "C" {
+
+const char* bsh_last_error(void) { return g_err.c_str(); }
+
+void* bsh_create(int max_surfel_count, float raw_to_float_depth, float baseline_fx, int sparse_surfel_cell_size,
+                 float surfel_merge_dist_factor, int min_obs_boot1, int min_obs_boot2, int min_obs,
+                 const float* color_params, int color_w, int color_h, const float* depth_params, int depth_w, int depth_h,
+                 int pyramid_level_for_color, int use_depth_residuals, int use_descriptor_residuals, int device) {
+  try {
+    return new DirectBA(max_surfel_count, raw_to_float_depth, baseline_fx, sparse_surfel_cell_size, surfel_merge_dist_factor, min_obs_boot1,
+                        min_obs_boot2, min_obs, PinholeCamera4f(color_w, color_h, color_params), PinholeCamera4f(depth_w, depth_h, depth_params),
+                        pyramid_level_for_color, use_depth_residuals != 0, use_descriptor_residuals != 0, nullptr, SE3f(), device);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+void bsh_destroy(void* ba) { delete static_cast<DirectBA*>(ba); }
+
+int bsh_add_keyframe(void* ba_, void* stream, uint32_t frame_index, float min_depth, float max_depth, const uint16_t* depth,
+                     const uint16_t* normals, const uint16_t* radius, const uint8_t* color, const float* pose7) {
+  DirectBA* ba = static_cast<DirectBA*>(ba_);
+  try {
+    auto kf = std::make_shared<Keyframe>(static_cast<hipStream_t>(stream), frame_index, min_depth, max_depth, ba->depth_camera().width(),
+                                         ba->depth_camera().height(), depth, normals, radius, reinterpret_cast<const uchar4_t*>(color),
+                                         pose_from7(pose7));
+    ba->AddKeyframe(kf);
+    return kf->id();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+int bsh_set_surfels(void* ba, void* stream, const float* rows, size_t pitch_bytes, uint32_t count) {
+  BSH_TRY(static_cast<DirectBA*>(ba)->SetSurfels(static_cast<hipStream_t>(stream), rows, pitch_bytes, count));
+}
+int bsh_get_surfels(void* ba, void* stream, float* rows, size_t pitch_bytes, int nrows) {
+  BSH_TRY(static_cast<DirectBA*>(ba)->GetSurfels(static_cast<hipStream_t>(stream), rows, pitch_bytes, nrows));
+}
+int bsh_get_active_surfels(void* ba, void* stream, uint8_t* out) {
+  BSH_TRY(static_cast<DirectBA*>(ba)->GetActiveSurfels(static_cast<hipStream_t>(stream), out));
+}
+uint32_t bsh_surfels_size(void* ba) { return static_cast<DirectBA*>(ba)->surfels_size(); }
+int bsh_keyframe_count(void* ba) { return static_cast<int>(static_cast<DirectBA*>(ba)->keyframes().size()); }
+
+int bsh_get_keyframe_pose(void* ba, int id, float* pose7) {
+  BSH_TRY(pose_to7(static_cast<DirectBA*>(ba)->keyframes().at(id)->global_T_frame(), pose7));
+}
+int bsh_set_keyframe_pose(void* ba, int id, const float* pose7) {
+  BSH_TRY(static_cast<DirectBA*>(ba)->keyframes().at(id)->set_global_T_frame(pose_from7(pose7)));
+}
+int bsh_get_keyframe_activation(void* ba, int id) { return static_cast<int>(static_cast<DirectBA*>(ba)->keyframes().at(id)->activation()); }
+int bsh_set_keyframe_activation(void* ba, int id, int activation) {
+  BSH_TRY(static_cast<DirectBA*>(ba)->keyframes().at(id)->SetActivation(static_cast<Keyframe::Activation>(activation)));
+}
+int bsh_keyframe_covisibility(void* ba, int id, int* out, int capacity) {
+  auto& list = static_cast<DirectBA*>(ba)->keyframes().at(id)->co_visibility_list();
+  const int n = static_cast<int>(list.size());
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = list[i];
+  return n;
+}
+// Replaces a keyframe's depth / normals image (the reference's tests do this through const_cast, e.g.
+// BS/test/test_geometry_optimization_geometric_residual.cc:124-139).
+int bsh_upload_keyframe_depth(void* ba, void* stream, int id, const uint16_t* depth) {
+  BSH_TRY({
+    auto& kf = static_cast<DirectBA*>(ba)->keyframes().at(id);
+    kf->mutable_depth_buffer().Upload(static_cast<hipStream_t>(stream), depth, static_cast<size_t>(kf->depth_buffer().width()) * 2);
+  });
+}
+int bsh_upload_keyframe_normals(void* ba, void* stream, int id, const uint16_t* normals) {
+  BSH_TRY({
+    auto& kf = static_cast<DirectBA*>(ba)->keyframes().at(id);
+    kf->mutable_normals_buffer().Upload(static_cast<hipStream_t>(stream), normals, static_cast<size_t>(kf->normals_buffer().width()) * 2);
+  });
+}
+
+int bsh_set_options(void* ba, int batched_pose_optimization, int pcg_gauge_keyframe, int texture_mode) {
+  BSH_TRY({
+    DirectBA* b = static_cast<DirectBA*>(ba);
+    b->SetBatchedPoseOptimization(batched_pose_optimization != 0);
+    b->SetPCGGaugeKeyframe(pcg_gauge_keyframe);
+    b->SetTextureMode(texture_mode);
+  });
+}
+int bsh_set_allreduce(void* ba, bslam_allreduce_fn fn, void* user) { BSH_TRY(static_cast<DirectBA*>(ba)->SetAllReduce(fn, user)); }
+
+int bsh_estimate_frame_pose(void* ba_, void* stream, int keyframe_id, const float* init7, float* out7) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    const auto& kf = ba->keyframes().at(keyframe_id);
+    SE3f out;
+    ba->EstimateFramePose(static_cast<hipStream_t>(stream), pose_from7(init7), kf->depth_buffer(), kf->normals_buffer(), kf->color_buffer(), &out, false);
+    pose_to7(out, out7);
+  });
+}
+
+int bsh_bundle_adjustment(void* ba, void* stream, int optimize_depth_intrinsics, int optimize_color_intrinsics, int do_surfel_updates,
+                          int optimize_poses, int optimize_geometry, int min_iterations, int max_iterations, int use_pcg,
+                          int active_keyframe_window_start, int active_keyframe_window_end, int increase_ba_iteration_count,
+                          int pcg_max_inner_iterations, int* iterations_done, int* converged) {
+  BSH_TRY({
+    bool conv = false;
+    int iters = 0;
+    static_cast<DirectBA*>(ba)->BundleAdjustment(static_cast<hipStream_t>(stream), optimize_depth_intrinsics != 0, optimize_color_intrinsics != 0,
+                                                 do_surfel_updates != 0, optimize_poses != 0, optimize_geometry != 0, min_iterations, max_iterations,
+                                                 use_pcg != 0, active_keyframe_window_start, active_keyframe_window_end,
+                                                 increase_ba_iteration_count != 0, &iters, &conv, 0, nullptr, pcg_max_inner_iterations);
+    if (iterations_done) *iterations_done = iters;
+    if (converged) *converged = conv ? 1 : 0;
+  });
+}
+
+int bsh_get_intrinsics(void* ba_, float* color4, float* depth4, float* a) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    std::memcpy(color4, ba->color_camera().parameters(), 16);
+    std::memcpy(depth4, ba->depth_camera().parameters(), 16);
+    *a = ba->a();
+  });
+}
+
+}  // extern "C"
