@@ -4,7 +4,7 @@ keyframe without merging (19 200 surfels per keyframe).
 
 Pure numpy input synthesis in the formats the hot path reads (BS/kernels.cuh:38-93,
 BS/util.cuh:105-130); it does not go through the reference's
-preprocessing kernels and it never touches oracle/.
+preprocessing kernels and it uses nothing but numpy.
 """
 import ctypes as C
 
