@@ -112,15 +112,25 @@ static SurfelRowsRW surfel_rows_rw(const bslam_buffer2d* s, const bslam_buffer2d
 // Uploads a keyframe table through pinned staging.  The staging buffer is only rewritten after
 // the previous upload has been consumed (stream-ordered, so we wait for the stream first if the
 // same staging is still in flight -- uploads are a few KB and the wait is normally a no-op).
-static int upload_kf_table(bslam_context* ctx, hipStream_t stream, const std::vector<KfDev>& table) {
+static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<KfDev>& table, const CamConsts& c) {
   const size_t bytes = table.size() * sizeof(KfDev);
   int rc = ctx->kf_table.reserve(bytes);
   if (rc) return rc;
   rc = ctx->staging.reserve(bytes);
   if (rc) return rc;
+  const size_t rec_per_kf = (size_t)c.width * c.height;
+  if ((rc = ctx->records.reserve(table.size() * rec_per_kf * sizeof(uint2)))) return rc;
+  for (size_t k = 0; k < table.size(); ++k) table[k].records = (const uint2*)ctx->records.ptr + k * rec_per_kf;
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));
   std::memcpy(ctx->staging.ptr, table.data(), bytes);
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, ctx->staging.ptr, bytes, hipMemcpyHostToDevice, stream));
+  // derived pixel records: rebuilt on every call because the caller owns (and may have rewritten) the
+  // depth / normal / cfactor images between calls
+  if (!table.empty() && table[0].depth != nullptr) {
+    hipLaunchKernelGGL(build_records_kernel, dim3((unsigned)((c.width + 255) / 256), (unsigned)c.height, (unsigned)table.size()), dim3(256), 0, stream,
+                       c, (const KfDev*)ctx->kf_table.ptr, (uint2*)ctx->records.ptr);
+    BSLAM_HIP_TRY(hipGetLastError());
+  }
   return BSLAM_OK;
 }
 
@@ -263,8 +273,8 @@ int bslam_debug_count_pairs(
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   std::vector<KfDev> table;
   if ((rc = build_kf_table(depth_camera, nullptr, false, keyframe_count, keyframes, &table))) return rc;
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   unsigned long long* d_out = (unsigned long long*)((uint8_t*)ctx->misc.ptr + 64);
   BSLAM_HIP_TRY(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(count_pairs_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
@@ -300,8 +310,8 @@ int bslam_accumulate_pose_estimation_coeffs(
 
   std::vector<KfDev> table(1);
   fill_kf(&table[0], depth_buffer, normals_buffer, use_descriptor_residuals ? color_buffer : nullptr, frame_T_global_estimate, nullptr, BSLAM_KF_ACTIVE, 0);
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   int tiles = 0;
   if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, 1, surfels_size, surfels, nullptr, &tiles))) return rc;
   if ((rc = ctx->staging2.reserve(kRow * sizeof(float)))) return rc;
@@ -332,8 +342,8 @@ int bslam_accumulate_pose_coeffs_batched(
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   std::vector<KfDev> table;
   if ((rc = build_kf_table(depth_camera, color_camera, use_descriptor_residuals != 0, keyframe_count, keyframes, &table))) return rc;
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   int tiles = 0;
   if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, nullptr, &tiles))) return rc;
   if (Hb || counts) {
@@ -375,7 +385,8 @@ int bslam_estimate_frame_poses_batched(
     std::memcpy(st.t, poses[k].t, sizeof(float) * 3);
     st.converged = (keyframes[k].activation == BSLAM_KF_INACTIVE) ? 1 : 0;
   }
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   const size_t state_bytes = states.size() * sizeof(PoseState);
   if ((rc = ctx->pose_state.reserve(state_bytes))) return rc;
   if ((rc = ctx->staging2.reserve(state_bytes + 64))) return rc;
@@ -383,7 +394,6 @@ int bslam_estimate_frame_poses_batched(
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->pose_state.ptr, ctx->staging2.ptr, state_bytes, hipMemcpyHostToDevice, stream));
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));
 
-  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
   PoseState* d_states = (PoseState*)ctx->pose_state.ptr;
   int* d_active = (int*)ctx->misc.ptr;
   int* h_active = (int*)((uint8_t*)ctx->staging2.ptr + state_bytes);
@@ -438,8 +448,9 @@ static int geometry_common(bslam_context* ctx, hipStream_t stream, const bslam_c
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   std::vector<KfDev> table;
   if ((rc = build_kf_table(depth_camera, color_camera, need_color, keyframe_count, keyframes, &table))) return rc;
-  if (table.empty()) table.resize(1);   // keep the table pointer valid; kf_count = 0 makes every loop empty
-  return upload_kf_table(ctx, stream, table);
+  if (table.empty()) { table.resize(1); std::memset(&table[0], 0, sizeof(KfDev)); }   // keep the table pointer valid; kf_count = 0 makes every loop empty
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, dp);
+  return upload_kf_table(ctx, stream, table, c);
 }
 
 int bslam_update_surfel_activation(
@@ -506,8 +517,8 @@ int bslam_debug_association(
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   std::vector<KfDev> table;
   if ((rc = build_kf_table(depth_camera, nullptr, false, 1, keyframe, &table))) return rc;
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   hipLaunchKernelGGL(association_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr,
                      surfel_rows_rw(surfels, nullptr, surfels_size), out_pixel);
   BSLAM_HIP_TRY(hipGetLastError());
@@ -527,8 +538,8 @@ int bslam_debug_pose_residuals(
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   std::vector<KfDev> table;
   if ((rc = build_kf_table(depth_camera, color_camera, use_descriptor_residuals != 0, 1, keyframe, &table))) return rc;
-  if ((rc = upload_kf_table(ctx, stream, table))) return rc;
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   const dim3 grid((surfels_size + 255) / 256), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   const SurfelRowsRW rows = surfel_rows_rw(surfels, nullptr, surfels_size);

@@ -71,6 +71,7 @@ struct bslam_context {
   int tex_mode = BSLAM_TEX_FIXED_POINT_1_8;
   int cu_count = 256;
   bslam::Slab kf_table;      // KfDev[K]
+  bslam::Slab records;       // uint2[K][h][w] derived pixel records
   bslam::Slab partials;      // float[tiles][K][32]
   bslam::Slab coeffs;        // float[K][32]
   bslam::Slab pose_state;    // PoseState[K]

@@ -71,6 +71,9 @@ struct KfDev {
   const uint8_t* depth;    uint32_t depth_pitch;
   const uint8_t* normals;  uint32_t normals_pitch;
   const uint8_t* color;    uint32_t color_pitch;
+  // derived per-pixel records {f32 calibrated depth, u16 pixel normal, u16 raw depth}, row pitch in
+  // records = image width (library-owned, rebuilt by build_records_kernel)
+  const uint2* records;
   M34 frame_T_global;
   float global_R_frame[9];
   int activation;
@@ -254,7 +257,28 @@ struct Proj {
   int px, py;
   f2 pxy;
   uint32_t pixel_normal;  // raw u16 normal of the associated pixel
+  uint32_t raw_depth;     // raw u16 depth of the associated pixel
 };
+
+// One derived record per pixel: the calibrated depth depends only on the pixel (raw depth, cfactor
+// cell, a), so its two IEEE divisions (+ expf) are paid once per pixel per call instead of once per
+// (surfel, keyframe) pair, and depth + pixel normal arrive in a single 8-byte gather.
+// Same arithmetic as RawToCalibratedDepth (BS/util.cuh:46-53), hence bit-identical depths.
+__global__ __launch_bounds__(256) void build_records_kernel(CamConsts c, const KfDev* __restrict__ kfs, uint2* __restrict__ records) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int k = blockIdx.z;
+  if (x >= c.width) return;
+  const KfDev& kf = kfs[k];
+  const uint32_t measured = *(const uint16_t*)(kf.depth + (size_t)y * kf.depth_pitch + 2 * (size_t)x);
+  const uint32_t normal = *(const uint16_t*)(kf.normals + (size_t)y * kf.normals_pitch + 2 * (size_t)x);
+  float depth = 0.f;
+  if (!(measured & BSLAM_INVALID_DEPTH_BIT)) {
+    const float cf = *(const float*)((const uint8_t*)c.cfactor + (size_t)(y / c.cell) * c.cfactor_pitch + 4 * (size_t)(x / c.cell));
+    depth = raw_to_calibrated_depth(c.a, cf, c.raw_to_float_depth, measured);
+  }
+  records[((size_t)k * c.height + y) * c.width + x] = make_uint2(__float_as_uint(depth), normal | (measured << 16));
+}
 
 // gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
 // associated with the pixel it projects to.
@@ -271,16 +295,19 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   r->py = f2i(r->pxy.y);
   if (r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height) return false;
   // IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127
-  const uint32_t measured = *(const uint16_t*)(kf.depth + (size_t)r->py * kf.depth_pitch + 2 * (size_t)r->px);
-  if (measured & BSLAM_INVALID_DEPTH_BIT) return false;
-  const float cf = *(const float*)((const uint8_t*)c.cfactor + (size_t)(r->py / c.cell) * c.cfactor_pitch + 4 * (size_t)(r->px / c.cell));
-  r->depth = raw_to_calibrated_depth(c.a, cf, c.raw_to_float_depth, measured);
+  const uint2 rec = kf.records[(size_t)r->py * c.width + r->px];
+  if (rec.y & ((uint32_t)BSLAM_INVALID_DEPTH_BIT << 16)) return false;
+  r->depth = __uint_as_float(rec.x);
+  r->raw_depth = rec.y >> 16;
   r->n_local = rot34(T, gn);
   const float stddev = depth_stddev(nx_of(c, (float)r->px), ny_of(c, (float)r->py), r->depth, r->n_local, c.baseline_fx);
   if (fabsf(r->local.z - r->depth) > kDepthTukey * stddev) return false;
-  const float dist = norm3(r->local);
-  if ((1.0f / dist) * dot(r->local, r->n_local) > 0) return false;
-  r->pixel_normal = *(const uint16_t*)(kf.normals + (size_t)r->py * kf.normals_pitch + 2 * (size_t)r->px);
+  // reference: (1.0f / Norm(local)) * Dot(local, n_local) > 0  (:107-111).  1 / |local| is a positive,
+  // finite, normal number for every |local| in [2^-126, 2^126] (and |local| >= local.z > 0 here), so the
+  // product has the sign of the dot product unless it underflows, which needs |dot| < 2^-23 * 2^-126 * |local|:
+  // the sign test is evaluated on the dot product directly (saves a sqrt and a division per pair).
+  if (dot(r->local, r->n_local) > 0) return false;
+  r->pixel_normal = rec.y & 0xffffu;
   const f3 pn = u16_to_image_space_normal(r->pixel_normal);
   if (dot(r->n_local, pn) < kCosNormalCompat) return false;
   return true;

@@ -68,7 +68,7 @@ __device__ __forceinline__ DepthIntrinsicsTerms depth_intrinsics_terms(const Cam
   DepthIntrinsicsTerms t;
   const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
   const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
-  const uint32_t measured = *(const uint16_t*)(kf.depth + (size_t)p.py * kf.depth_pitch + 2 * (size_t)p.px);
+  const uint32_t measured = p.raw_depth;
   const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)measured);
   const float exp_inv_depth = expf(-c.a * raw_inv_depth);
   const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
