@@ -86,8 +86,9 @@ SIGNATURES = {
     "bslam_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
     "bslam_destroy": (C.c_int, [C.c_void_p]),
     "bslam_set_texture_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_set_xcd_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "bslam_profile_read": (C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_float)]),
+    "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),
     "bslam_debug_count_pairs": (C.c_int, [
         C.c_void_p, C.c_void_p, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(C.c_uint64), P(C.c_uint64)]),
     "bslam_accumulate_pose_estimation_coeffs": (C.c_int, [

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -152,6 +153,75 @@ static int build_kf_table(const bslam_camera4f* depth_camera, const bslam_camera
   return BSLAM_OK;
 }
 
+// Builds (or re-uses) the XCD-aware granule order for a surfel buffer: centroid per granule on the
+// device, Morton sort on the host (a few thousand keys), uploaded once and cached until the buffer
+// or its size changes.  The order only steers locality, never results' validity.
+static uint32_t morton10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buffer2d* surfels, uint32_t surfels_size, int R, Schedule* out) {
+  const uint32_t G = (surfels_size + kGranule - 1) / kGranule;
+  out->granules = G;
+  out->slots = (G + (uint32_t)R - 1) / (uint32_t)R;
+  out->slots_per_xcd = (out->slots + 7) / 8;
+  out->order = nullptr;
+  if (!ctx->use_schedule || G < 64) return BSLAM_OK;   // tiny problems: identity order
+  if (ctx->order_key_ptr == surfels->address && ctx->order_key_size == surfels_size && ctx->order_key_pitch == surfels->pitch) {
+    out->order = (const uint32_t*)ctx->order.ptr;
+    return BSLAM_OK;
+  }
+  int rc = ctx->order.reserve((size_t)G * sizeof(uint32_t) + (size_t)G * sizeof(float4));
+  if (rc) return rc;
+  uint32_t* d_order = (uint32_t*)ctx->order.ptr;
+  float4* d_cent = (float4*)((uint8_t*)ctx->order.ptr + (((size_t)G * sizeof(uint32_t) + 15) / 16) * 16);
+  if ((rc = ctx->order.reserve((size_t)((uint8_t*)(d_cent + G) - (uint8_t*)ctx->order.ptr)))) return rc;
+  d_order = (uint32_t*)ctx->order.ptr;
+  d_cent = (float4*)((uint8_t*)ctx->order.ptr + (((size_t)G * sizeof(uint32_t) + 15) / 16) * 16);
+  auto row = [&](int r) { return (const float*)((const uint8_t*)surfels->address + (size_t)r * surfels->pitch); };
+  hipLaunchKernelGGL(granule_centroid_kernel, dim3(G), dim3(kGranule), 0, stream, row(BSLAM_SURFEL_X), row(BSLAM_SURFEL_Y), row(BSLAM_SURFEL_Z), surfels_size, d_cent);
+  BSLAM_HIP_TRY(hipGetLastError());
+  std::vector<float4> cent(G);
+  BSLAM_HIP_TRY(hipMemcpyAsync(cent.data(), d_cent, (size_t)G * sizeof(float4), hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+  for (uint32_t g = 0; g < G; ++g) {
+    if (cent[g].w <= 0.f) continue;
+    const float v[3] = {cent[g].x, cent[g].y, cent[g].z};
+    for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], v[d]); hi[d] = std::max(hi[d], v[d]); }
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> keyed(G);
+  for (uint32_t g = 0; g < G; ++g) {
+    uint32_t key = 0x3fffffffu;   // empty granules last
+    if (cent[g].w > 0.f) {
+      const float v[3] = {cent[g].x, cent[g].y, cent[g].z};
+      uint32_t q[3];
+      for (int d = 0; d < 3; ++d) {
+        const float span = hi[d] - lo[d];
+        const float t = span > 0.f ? (v[d] - lo[d]) / span : 0.f;
+        q[d] = (uint32_t)std::min(1023.f, std::max(0.f, t * 1023.f));
+      }
+      key = morton10(q[0]) | (morton10(q[1]) << 1) | (morton10(q[2]) << 2);
+    }
+    keyed[g] = std::make_pair(key, g);
+  }
+  std::sort(keyed.begin(), keyed.end());
+  std::vector<uint32_t> order(G);
+  for (uint32_t g = 0; g < G; ++g) order[g] = keyed[g].second;
+  BSLAM_HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)G * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));   // `order` is a stack-local vector
+  ctx->order_key_ptr = surfels->address;
+  ctx->order_key_size = surfels_size;
+  ctx->order_key_pitch = surfels->pitch;
+  out->order = d_order;
+  return BSLAM_OK;
+}
+
 // Chooses how many keyframes one block walks: enough blocks to fill 256 CUs several times over.
 static int choose_kfs_per_block(int tiles, int kf_count) {
   const int target_blocks = 8192;
@@ -164,25 +234,30 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
                                   int* tiles_out) {
-  const int tiles = (int)((surfels_size + kPoseTile - 1) / kPoseTile);
+  Schedule sc;
+  int rc = make_schedule(ctx, stream, surfels, surfels_size, kPoseR, &sc);
+  if (rc) return rc;
+  const int tiles = (int)sc.slots;
   *tiles_out = tiles;
-  int rc = ctx->partials.reserve((size_t)tiles * kf_count * kRow * sizeof(float));
+  const int rows_per_kf = tiles * (kPoseThreads / 64);   // one partial row per (slot, wave)
+  rc = ctx->partials.reserve((size_t)rows_per_kf * kf_count * kRow * sizeof(float));
   if (rc) return rc;
   rc = ctx->coeffs.reserve((size_t)kf_count * kRow * sizeof(float));
   if (rc) return rc;
   const int per_block = choose_kfs_per_block(tiles, kf_count);
-  dim3 grid((unsigned)tiles, (unsigned)((kf_count + per_block - 1) / per_block));
+  const unsigned chunks = (unsigned)((kf_count + per_block - 1) / per_block);
+  dim3 grid(8u * sc.slots_per_xcd * chunks);
   const SurfelRows rows = surfel_rows(surfels, surfels_size);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   float* partials = (float*)ctx->partials.ptr;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, rows, partials, states);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
   }
   BSLAM_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count), dim3(256), 0, stream, partials, tiles, kf_count, (float*)ctx->coeffs.ptr, states);
+  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count), dim3(256), 0, stream, partials, rows_per_kf, kf_count, (float*)ctx->coeffs.ptr, states);
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -218,9 +293,9 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->order.release();
   ctx->staging.release(); ctx->staging2.release();
-  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(ev);
+  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
   delete ctx;
   return BSLAM_OK;
@@ -233,31 +308,38 @@ int bslam_set_texture_mode(bslam_context* ctx, int mode) {
   return BSLAM_OK;
 }
 
-int bslam_profile_enable(bslam_context* ctx, int enable) {
+int bslam_set_xcd_schedule(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
-  ctx->profiling = enable != 0;
-  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(ev);
-  ctx->prof_pending.clear();
-  ctx->prof_launches = 0;
-  ctx->prof_ms = 0.f;
+  ctx->use_schedule = enable != 0;
+  ctx->order_key_ptr = nullptr;
   return BSLAM_OK;
 }
 
-int bslam_profile_read(bslam_context* ctx, int32_t* launches, float* total_ms) {
+int bslam_profile_enable(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->profiling = enable != 0;
+  for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
+  ctx->prof_pending.clear();
+  for (int t = 0; t < 4; ++t) { ctx->prof_launches[t] = 0; ctx->prof_ms[t] = 0.f; }
+  return BSLAM_OK;
+}
+
+int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float* total_ms) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  if (kernel < 0 || kernel >= 4) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown kernel tag %d", kernel);
   for (auto& ev : ctx->prof_pending) {
-    BSLAM_HIP_TRY(hipEventSynchronize(ev.second));
+    BSLAM_HIP_TRY(hipEventSynchronize(ev.stop));
     float ms = 0.f;
-    BSLAM_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
-    ctx->prof_ms += ms;
-    ctx->prof_launches += 1;
-    ctx->prof_pool.push_back(ev);
+    BSLAM_HIP_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
+    ctx->prof_ms[ev.tag] += ms;
+    ctx->prof_launches[ev.tag] += 1;
+    ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   }
   ctx->prof_pending.clear();
-  if (launches) *launches = ctx->prof_launches;
-  if (total_ms) *total_ms = ctx->prof_ms;
-  ctx->prof_launches = 0;
-  ctx->prof_ms = 0.f;
+  if (launches) *launches = ctx->prof_launches[kernel];
+  if (total_ms) *total_ms = ctx->prof_ms[kernel];
+  ctx->prof_launches[kernel] = 0;
+  ctx->prof_ms[kernel] = 0.f;
   return BSLAM_OK;
 }
 
@@ -462,7 +544,9 @@ int bslam_update_surfel_activation(
   int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
-  hipLaunchKernelGGL(activation_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+  Schedule sc;
+  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  hipLaunchKernelGGL(activation_kernel, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
                      surfel_rows_rw(surfels, active_surfels, surfels_size));
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
@@ -477,7 +561,9 @@ int bslam_update_surfel_normals(
   int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
-  hipLaunchKernelGGL((geometry_kernel<0, true>), dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+  Schedule sc;
+  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  hipLaunchKernelGGL((geometry_kernel<0, true>), dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
                      surfel_rows_rw(surfels, active_surfels, surfels_size));
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
@@ -495,12 +581,17 @@ int bslam_optimize_geometry_iteration(
   int rc = geometry_common(ctx, stream, color_camera, depth_camera, depth_params, use_descriptor_residuals != 0, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
-  const dim3 grid((surfels_size + 255) / 256), block(256);
+  Schedule sc;
+  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  const dim3 grid(8u * sc.slots_per_xcd), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
-  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_kernel<1, true>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
-  else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
-  else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, rows);
+  {
+  ProfScope prof(ctx, stream, 1);
+  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_kernel<1, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  }
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }

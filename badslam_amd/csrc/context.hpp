@@ -78,19 +78,26 @@ struct bslam_context {
   bslam::Slab misc;          // small device scalars
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
+  // XCD-aware schedule (granule order), cached per surfel buffer
+  bslam::Slab order;
+  bool use_schedule = true;
+  const void* order_key_ptr = nullptr;
+  uint32_t order_key_size = 0;
+  size_t order_key_pitch = 0;
   // kernel timing (bslam_profile_*)
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+  struct ProfEntry { hipEvent_t start, stop; int tag; };
+  std::vector<ProfEntry> prof_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-  int prof_launches = 0;
-  float prof_ms = 0.f;
+  int prof_launches[4] = {0, 0, 0, 0};
+  float prof_ms[4] = {0.f, 0.f, 0.f, 0.f};
 };
 
 namespace bslam {
 // Brackets one kernel launch with events when profiling is on.
 struct ProfScope {
-  bslam_context* ctx; hipStream_t stream; std::pair<hipEvent_t, hipEvent_t> ev; bool on;
-  ProfScope(bslam_context* c, hipStream_t s) : ctx(c), stream(s), on(c->profiling) {
+  bslam_context* ctx; hipStream_t stream; std::pair<hipEvent_t, hipEvent_t> ev; bool on; int tag;
+  ProfScope(bslam_context* c, hipStream_t s, int tag_ = 0) : ctx(c), stream(s), on(c->profiling), tag(tag_) {
     if (!on) return;
     if (!ctx->prof_pool.empty()) { ev = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
     else { hipError_t e = hipEventCreate(&ev.first); e = hipEventCreate(&ev.second); (void)e; }
@@ -99,7 +106,7 @@ struct ProfScope {
   ~ProfScope() {
     if (!on) return;
     hipError_t e = hipEventRecord(ev.second, stream); (void)e;
-    ctx->prof_pending.push_back(ev);
+    ctx->prof_pending.push_back(bslam_context::ProfEntry{ev.first, ev.second, tag});
   }
 };
 }  // namespace bslam

@@ -341,6 +341,41 @@ __device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 
 }
 
 // ---------------------------------------------------------------------------------------------
+// XCD-aware work schedule.  Surfels are handled in granules of 256 consecutive columns.  The
+// host sorts the granules along a Morton curve of their centroids (`order`), and the sorted
+// sequence is cut into 8 contiguous ranges, one per XCD: workgroups are dealt round-robin over the
+// 8 XCDs (observed dispatch behaviour, used for speed only), so block b with b % 8 == x takes its
+// work from range x.  Each XCD then projects a compact part of the scene and touches only the
+// matching part of every keyframe image, instead of every XCD pulling every image through its own L2.
+// Any permutation is correct; a stale one only costs locality.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGranule = 256;
+
+struct Schedule {
+  const uint32_t* order;   // sorted position -> granule id (nullptr: identity)
+  uint32_t granules;       // ceil(S / 256)
+  uint32_t slots;          // ceil(granules / R): work items of R granules each
+  uint32_t slots_per_xcd;  // ceil(slots / 8)
+};
+
+// Work slot of block index b (of a 1-D launch of 8 * slots_per_xcd blocks), or false.
+__device__ __forceinline__ bool slot_of_block(const Schedule& sc, uint32_t b, uint32_t* slot) {
+  const uint32_t x = b & 7u, i = b >> 3;
+  const uint32_t s = x * sc.slots_per_xcd + i;
+  if (i >= sc.slots_per_xcd || s >= sc.slots) return false;
+  *slot = s;
+  return true;
+}
+
+// Surfel column of this thread for granule r of the slot (R granules per slot); >= size if none.
+__device__ __forceinline__ uint32_t surfel_of_slot(const Schedule& sc, uint32_t slot, int r, int R) {
+  const uint32_t pos = slot * (uint32_t)R + (uint32_t)r;
+  if (pos >= sc.granules) return 0xffffffffu;
+  const uint32_t g = sc.order ? sc.order[pos] : pos;
+  return g * kGranule + threadIdx.x;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -352,6 +387,30 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
+}
+
+// Sums 32 per-lane values across the 64 lanes of a wave with 32 exchanges instead of 32 x 6:
+// at every step a lane keeps one half of its values and trades the other half with lane ^ mask, so
+// the value count halves while the number of lanes summed doubles.  Afterwards lane l holds the
+// wave total of column (l >> 1) & 31 (both lanes of a pair hold it).  Fixed tree: deterministic.
+__device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
+  const uint32_t lane = threadIdx.x & 63u;
+#define BSLAM_TR_STEP(N, MASK)                                           \
+  {                                                                      \
+    const bool up = (lane & MASK) != 0;                                  \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {                      \
+      const float send = up ? v[i] : v[i + N];                           \
+      const float keep = up ? v[i + N] : v[i];                           \
+      v[i] = keep + __shfl_xor(send, MASK, 64);                          \
+    }                                                                    \
+  }
+  BSLAM_TR_STEP(16, 32)
+  BSLAM_TR_STEP(8, 16)
+  BSLAM_TR_STEP(4, 8)
+  BSLAM_TR_STEP(2, 4)
+  BSLAM_TR_STEP(1, 2)
+#undef BSLAM_TR_STEP
+  return v[0] + __shfl_xor(v[0], 1, 64);
 }
 
 }  // namespace bslam

@@ -23,8 +23,10 @@ struct SurfelRowsRW {
 };
 
 // SetSurfelInactiveKernel + K x DetermineActiveSurfelsKernel (BS/kernel_surfel_activation.cu:38-79)
-__global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
   if (i >= s.size) return;
   uint8_t flag = s.active[i] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
   const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
@@ -36,6 +38,28 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
     if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; break; }
   }
   s.active[i] = flag;
+}
+
+// Mean position of every granule of 256 surfels (NaN / deleted surfels ignored): input of the
+// host-side Morton sort that builds the XCD-aware schedule.
+__global__ __launch_bounds__(256) void granule_centroid_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                               uint32_t size, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * kGranule + threadIdx.x;
+  float vx = 0.f, vy = 0.f, vz = 0.f, n = 0.f;
+  if (i < size) {
+    const float a = x[i], b = y[i], cc = z[i];
+    if (a == a && b == b && cc == cc && fabsf(a) < 1e18f && fabsf(b) < 1e18f && fabsf(cc) < 1e18f) { vx = a; vy = b; vz = cc; n = 1.f; }
+  }
+  __shared__ float sm[4][4];
+  vx = wave_sum(vx); vy = wave_sum(vy); vz = wave_sum(vz); n = wave_sum(n);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = vx; sm[threadIdx.x >> 6][1] = vy; sm[threadIdx.x >> 6][2] = vz; sm[threadIdx.x >> 6][3] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int w = 0; w < 4; ++w) { s0 += sm[w][0]; s1 += sm[w][1]; s2 += sm[w][2]; s3 += sm[w][3]; }
+    const float inv = s3 > 0.f ? 1.f / s3 : 0.f;
+    out[blockIdx.x] = make_float4(s0 * inv, s1 * inv, s2 * inv, s3);
+  }
 }
 
 // Association probe: out[i] = py * width + px or 0xffffffff.
@@ -120,8 +144,10 @@ __global__ __launch_bounds__(256) void residual_probe_kernel(CamConsts c, const 
 //   kMode 1: normals, then position        (geometry-only,  BS/kernel_opt_geometry.cc:137-169)
 //   kMode 2: normals, then position + descriptors jointly   (BS/kernel_opt_geometry.cc:170-200)
 template <int kMode, bool kDepth>
-__global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
   if (i >= s.size) return;
   if (!(s.active[i] & BSLAM_SURFEL_ACTIVE_FLAG)) return;
   f3 gp = mk3(s.x[i], s.y[i], s.z[i]);

@@ -110,9 +110,11 @@ __device__ __forceinline__ DescTerms descriptor_terms(const CamConsts& c, const 
 // ---------------------------------------------------------------------------------------------
 template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRows s, PcgParams P,
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
-  const int tile = blockIdx.x;
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float red[2][4][32];
   __shared__ float redg[4][32];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   float ar[kPcgR][3], aM[kPcgR][3];
 #pragma unroll
   for (int r = 0; r < kPcgR; ++r) {
-    const uint32_t i = (uint32_t)tile * kPcgTile + r * kPcgThreads + threadIdx.x;
+    const uint32_t i = surfel_of_slot(sc, slot, r, kPcgR);
     valid[r] = i < s.size;
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
@@ -322,9 +324,11 @@ __global__ __launch_bounds__(64) void pcg_glob_reduce_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRows s, PcgParams P,
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
-  const int tile = blockIdx.x;
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float red[2][4][32];
   __shared__ float redg[4][32];
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
   float ps[kPcgR][3], ag[kPcgR][3];
 #pragma unroll
   for (int r = 0; r < kPcgR; ++r) {
-    const uint32_t i = (uint32_t)tile * kPcgTile + r * kPcgThreads + threadIdx.x;
+    const uint32_t i = surfel_of_slot(sc, slot, r, kPcgR);
     valid[r] = i < s.size;
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);

@@ -9,10 +9,12 @@
 //   * one launch covers (surfel tiles) x (keyframe chunks); a thread keeps kR surfels in
 //     registers (position + decoded normal) and walks the keyframes of its chunk, so surfel
 //     bytes are read once per chunk instead of once per keyframe;
-//   * the 21 + 6 (+ cost, count) coefficients are accumulated per thread over its kR surfels,
-//     reduced across the wave with shuffles and across the 4 waves through LDS, and written as
-//     one 32-float row per (tile, keyframe); a second kernel sums the rows over tiles in a
-//     fixed order: deterministic, no float atomics;
+//   * the 21 + 6 (+ cost, count) coefficients are accumulated per thread over its kR surfels
+//     (fused multiply-adds: these sums are compared at 1e-4, only the association predicates
+//     need bit-exact arithmetic), reduced across the wave with a transposing butterfly
+//     (32 exchanges for 32 values) and written as one coalesced 32-float row per (wave, keyframe):
+//     no LDS, no barrier in the keyframe loop; a second kernel sums the rows in a fixed order:
+//     deterministic, no float atomics;
 //   * the 6x6 solve, SE3 update and convergence test run on the device (one thread per
 //     keyframe), all keyframes advance in lock-step.
 #pragma once
@@ -49,28 +51,33 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
   int idx = 0;
 #pragma unroll
   for (int row = 0; row < 6; ++row) {
+    const float wj = w * J[row];
 #pragma unroll
     for (int col = row; col < 6; ++col) {
-      acc[idx] += w * J[row] * J[col];
+      acc[idx] = __builtin_fmaf(wj, J[col], acc[idx]);
       ++idx;
     }
   }
   const float wr = w * raw;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) acc[21 + i] += wr * J[i];
+  for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fmaf(wr, J[i], acc[21 + i]);
 }
 
 template <bool kDepth, bool kDesc>
 __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block,
+    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
     SurfelRows s, float* __restrict__ partials, const PoseState* __restrict__ states) {
-  const int tile = blockIdx.x;
-  const int kf_begin = blockIdx.y * kfs_per_block;
+  // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
+  // blocks run chunk-major over that XCD's range of surfel slots.
+  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const uint32_t chunk = j / sc.slots_per_xcd, local = j - chunk * sc.slots_per_xcd;
+  uint32_t slot;
+  if (!slot_of_block(sc, (local << 3) | xcd, &slot)) return;
+  const int tile = (int)slot;
+  const int kf_begin = (int)chunk * kfs_per_block;
   const int kf_end = min(kf_count, kf_begin + kfs_per_block);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-
-  __shared__ float red[2][kPoseThreads / 64][kRow];
 
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
   float r2[kPoseR], d1[kPoseR], d2[kPoseR];
 #pragma unroll
   for (int r = 0; r < kPoseR; ++r) {
-    const uint32_t i = (uint32_t)tile * kPoseTile + r * kPoseThreads + threadIdx.x;
+    const uint32_t i = surfel_of_slot(sc, slot, r, kPoseR);
     valid[r] = i < s.size;
     const uint32_t j = valid[r] ? i : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
@@ -86,13 +93,12 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
     if (kDesc) { r2[r] = s.radius_squared[j]; d1[r] = s.d1[j]; d2[r] = s.d2[j]; }
   }
 
-  int parity = 0;
   for (int k = kf_begin; k < kf_end; ++k) {
     if (states != nullptr && states[k].converged) continue;   // uniform
     const KfDev& kf = kfs[k];
-    float acc[kRowCost + 1];
+    float acc[kRow];
 #pragma unroll
-    for (int i = 0; i <= kRowCost; ++i) acc[i] = 0.f;
+    for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
     uint32_t count = 0;
 
 #pragma unroll
@@ -128,30 +134,16 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
       }
     }
 
-    // wave reduction (skipped when the whole wave saw nothing for this keyframe)
+    // wave reduction (skipped when the whole wave saw nothing for this keyframe); the residual
+    // count (<= 64 * kPoseR per wave) travels as an exactly representable float in column kRowCount
     const bool any = __any(count != 0);
+    float total = 0.f;
     if (any) {
-#pragma unroll
-      for (int i = 0; i <= kRowCost; ++i) acc[i] = wave_sum(acc[i]);
-      count = wave_sum_u32(count);
+      acc[kRowCount] = (float)count;
+      total = wave_transpose_sum32(acc);
     }
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i <= kRowCost; ++i) red[parity][wave][i] = any ? acc[i] : 0.f;
-      red[parity][wave][kRowCount] = __uint_as_float(any ? count : 0u);
-    }
-    __syncthreads();
-    if (threadIdx.x < kRow) {
-      float v = 0.f;
-      if (threadIdx.x < kRowCount) {
-        v = ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x];
-      } else if (threadIdx.x == kRowCount) {
-        v = __uint_as_float(__float_as_uint(red[parity][0][kRowCount]) + __float_as_uint(red[parity][1][kRowCount]) +
-                            __float_as_uint(red[parity][2][kRowCount]) + __float_as_uint(red[parity][3][kRowCount]));
-      }
-      partials[((size_t)tile * kf_count + k) * kRow + threadIdx.x] = v;
-    }
-    parity ^= 1;   // double-buffered LDS: one barrier per keyframe
+    if ((lane & 1) == 0)
+      partials[(((size_t)tile * (kPoseThreads / 64) + wave) * kf_count + k) * kRow + (lane >> 1)] = total;
   }
 }
 
@@ -166,9 +158,9 @@ __global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restric
   __shared__ float sm[8][kRow];
   float v = 0.f;
   uint32_t n = 0;
-  for (int t = sub; t < tiles; t += 8) {
+  for (int t = sub; t < tiles; t += 8) {   // `tiles` = number of partial rows per keyframe (slots x waves)
     const float p = partials[((size_t)t * kf_count + k) * kRow + col];
-    if (col == kRowCount) n += __float_as_uint(p); else v += p;
+    if (col == kRowCount) n += (uint32_t)p; else v += p;
   }
   sm[sub][col] = (col == kRowCount) ? __uint_as_float(n) : v;
   __syncthreads();

@@ -123,7 +123,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     launches, kms = C.c_int32(), C.c_float()
-    L.bslam_profile_read(ctx.handle, C.byref(launches), C.byref(kms))
+    L.bslam_profile_read(ctx.handle, 0, C.byref(launches), C.byref(kms))
+    glaunches, gms = C.c_int32(), C.c_float()
+    L.bslam_profile_read(ctx.handle, 1, C.byref(glaunches), C.byref(gms))
     L.bslam_profile_enable(ctx.handle, 0)
 
     if world > 1:
@@ -159,7 +161,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "pose_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_us": avg_launch_s * 1e6, "launches": launches.value,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "geometry_kernel": geometry_roofline(S, K, frac_inb, assoc.value / pairs_per_pass, use_desc, glaunches.value, gms.value)},
     }
 
     if rank == 0 and args.cpu_baseline and world == 1:
@@ -168,6 +171,17 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def geometry_roofline(S, K, frac_inb, frac_assoc, use_desc, launches, total_ms):
+    """Second kernel of the BA iteration: normals pass + position (or position+descriptor) pass per launch."""
+    if launches == 0 or total_ms <= 0:
+        return None
+    pairs = S * K
+    nbytes = pairs * (frac_inb * B_NORMALS + (1 - frac_inb) * B_REJECTED) + pairs * (frac_inb * B_POSITION[use_desc] + (1 - frac_inb) * B_REJECTED)
+    avg_s = total_ms / 1e3 / launches
+    ach = nbytes / avg_s / 1e9
+    return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": nbytes}
 
 
 def cpu_baseline(stack, K, use_desc, budget_s):

@@ -158,13 +158,20 @@ int bslam_destroy(bslam_context* ctx);
 /* Texture filtering mode (BSLAM_TEX_*), default BSLAM_TEX_FIXED_POINT_1_8. */
 int bslam_set_texture_mode(bslam_context* ctx, int mode);
 
+/* XCD-aware scheduling (default on): surfel granules are visited along a Morton curve of their
+ * centroids, one contiguous range per XCD, so that every XCD's L2 only sees the part of each
+ * keyframe image its part of the scene projects to.  Results do not depend on it except for the
+ * summation order of the per-keyframe sums; 0 restores index order (A/B measurements). */
+int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
+
 /* Kernel timing for the roofline line of bench.py (the role of the reference's cudaEvent
  * pairs, BS/direct_ba.h:513-532): while enabled, every launch of the dominant kernel of a
  * call (the surfel x keyframe pass) is bracketed by HIP events on the launch stream.
  * bslam_profile_read synchronises those events and returns launches and summed ms since
  * the last enable/read. */
 int bslam_profile_enable(bslam_context* ctx, int enable);
-int bslam_profile_read(bslam_context* ctx, int32_t* launches, float* total_ms);
+enum { BSLAM_PROF_POSE_ACCUMULATE = 0, BSLAM_PROF_GEOMETRY = 1, BSLAM_PROF_PCG_INIT = 2, BSLAM_PROF_PCG_STEP1 = 3 };
+int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float* total_ms);
 
 /* ------------------------------------------------------------------------- */
 /* Pose optimisation                                                          */
