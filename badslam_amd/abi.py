@@ -87,6 +87,8 @@ SIGNATURES = {
     "bslam_destroy": (C.c_int, [C.c_void_p]),
     "bslam_set_texture_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_set_xcd_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_set_keyframe_cache": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),
     "bslam_debug_count_pairs": (C.c_int, [

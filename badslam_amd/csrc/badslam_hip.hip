@@ -126,8 +126,20 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   std::memcpy(ctx->staging.ptr, table.data(), bytes);
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, ctx->staging.ptr, bytes, hipMemcpyHostToDevice, stream));
   // derived pixel records: rebuilt on every call because the caller owns (and may have rewritten) the
-  // depth / normal / cfactor images between calls
-  if (!table.empty() && table[0].depth != nullptr) {
+  // depth / normal / cfactor images between calls -- unless the caller promised otherwise
+  // (bslam_set_keyframe_cache) and nothing the records depend on has changed since they were built
+  bool rebuild = true;
+  if (ctx->keyframe_cache) {
+    std::vector<uint64_t> sig;
+    sig.reserve(table.size() * 4 + 8);
+    for (const KfDev& kf : table) { sig.push_back((uint64_t)kf.depth); sig.push_back((uint64_t)kf.normals); sig.push_back(((uint64_t)kf.depth_pitch << 32) | kf.normals_pitch); }
+    uint32_t fa, fr; std::memcpy(&fa, &c.a, 4); std::memcpy(&fr, &c.raw_to_float_depth, 4);
+    sig.push_back((uint64_t)c.cfactor); sig.push_back(((uint64_t)c.cfactor_pitch << 32) | (uint32_t)c.cell);
+    sig.push_back(((uint64_t)fa << 32) | fr); sig.push_back(((uint64_t)c.width << 32) | (uint32_t)c.height);
+    sig.push_back((uint64_t)ctx->records.ptr);
+    if (sig == ctx->records_signature) rebuild = false; else ctx->records_signature.swap(sig);
+  }
+  if (rebuild && !table.empty() && table[0].depth != nullptr) {
     hipLaunchKernelGGL(build_records_kernel, dim3((unsigned)((c.width + 255) / 256), (unsigned)c.height, (unsigned)table.size()), dim3(256), 0, stream,
                        c, (const KfDev*)ctx->kf_table.ptr, (uint2*)ctx->records.ptr);
     BSLAM_HIP_TRY(hipGetLastError());
@@ -240,7 +252,8 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   const int tiles = (int)sc.slots;
   *tiles_out = tiles;
   const int rows_per_kf = tiles * (kPoseThreads / 64);   // one partial row per (slot, wave)
-  rc = ctx->partials.reserve((size_t)rows_per_kf * kf_count * kRow * sizeof(float));
+  const size_t partial_floats = (size_t)rows_per_kf * kf_count * kRow;
+  rc = ctx->partials.reserve((partial_floats + (size_t)kf_count * kReduceParts * kRow) * sizeof(float));
   if (rc) return rc;
   rc = ctx->coeffs.reserve((size_t)kf_count * kRow * sizeof(float));
   if (rc) return rc;
@@ -252,12 +265,17 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   float* partials = (float*)ctx->partials.ptr;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, states);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   }
   BSLAM_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count), dim3(256), 0, stream, partials, rows_per_kf, kf_count, (float*)ctx->coeffs.ptr, states);
+  float* parts = partials + partial_floats;
+  // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a part
+  // at most rows * 256 -- exact in fp32 up to 2^24, i.e. up to 65k rows per part (134M surfels per keyframe)
+  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count, kReduceParts), dim3(256), 0, stream, (const float*)partials, rows_per_kf, kf_count, parts, states);
+  BSLAM_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -305,6 +323,19 @@ int bslam_set_texture_mode(bslam_context* ctx, int mode) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   if (mode != BSLAM_TEX_FIXED_POINT_1_8 && mode != BSLAM_TEX_EXACT_FLOAT) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown texture mode %d", mode);
   ctx->tex_mode = mode;
+  return BSLAM_OK;
+}
+
+int bslam_set_keyframe_cache(bslam_context* ctx, int enable) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->keyframe_cache = enable != 0;
+  ctx->records_signature.clear();
+  return BSLAM_OK;
+}
+
+int bslam_invalidate_keyframe_cache(bslam_context* ctx) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->records_signature.clear();
   return BSLAM_OK;
 }
 

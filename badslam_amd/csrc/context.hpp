@@ -78,6 +78,9 @@ struct bslam_context {
   bslam::Slab misc;          // small device scalars
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
+  // derived-record cache (bslam_set_keyframe_cache)
+  bool keyframe_cache = false;
+  std::vector<uint64_t> records_signature;
   // XCD-aware schedule (granule order), cached per surfel buffer
   bslam::Slab order;
   bool use_schedule = true;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 template <bool kDepth, bool kDesc>
 __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
-    SurfelRows s, float* __restrict__ partials, const PoseState* __restrict__ states) {
+    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states) {
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
   // blocks run chunk-major over that XCD's range of surfel slots.
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -143,40 +143,54 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
       total = wave_transpose_sum32(acc);
     }
     if ((lane & 1) == 0)
-      partials[(((size_t)tile * (kPoseThreads / 64) + wave) * kf_count + k) * kRow + (lane >> 1)] = total;
+      partials[((size_t)k * rows_per_kf + (size_t)tile * (kPoseThreads / 64) + wave) * kRow + (lane >> 1)] = total;
   }
 }
 
-// Sums the partial rows of one keyframe over all tiles in a fixed order.
-// grid = K, block = 256: thread t owns column t % 32 and tile residue t / 32.
-__global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restrict__ partials, int tiles, int kf_count,
-                                                           float* __restrict__ coeffs, const PoseState* __restrict__ states) {
-  const int k = blockIdx.x;
+// Sums the partial rows [k][row][32] of one keyframe in a fixed order, in two stages so that the
+// sum is spread over K x kReduceParts workgroups.  Stage A: block (k, part) sums its contiguous
+// range of rows (thread t owns column t % 32 and row residue t / 32); stage B adds the parts.
+constexpr int kReduceParts = 8;
+
+__global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
+                                                           float* __restrict__ parts, const PoseState* __restrict__ states) {
+  const int k = blockIdx.x, part = blockIdx.y;
   if (states != nullptr && states[k].converged) return;
   const int col = threadIdx.x & 31;
   const int sub = threadIdx.x >> 5;   // 0..7
+  const int per_part = (rows_per_kf + kReduceParts - 1) / kReduceParts;
+  const int row_begin = part * per_part, row_end = min(rows_per_kf, row_begin + per_part);
   __shared__ float sm[8][kRow];
+  const float* base = partials + (size_t)k * rows_per_kf * kRow;
   float v = 0.f;
-  uint32_t n = 0;
-  for (int t = sub; t < tiles; t += 8) {   // `tiles` = number of partial rows per keyframe (slots x waves)
-    const float p = partials[((size_t)t * kf_count + k) * kRow + col];
-    if (col == kRowCount) n += (uint32_t)p; else v += p;
-  }
-  sm[sub][col] = (col == kRowCount) ? __uint_as_float(n) : v;
+  for (int t = row_begin + sub; t < row_end; t += 8) v += base[(size_t)t * kRow + col];
+  sm[sub][col] = v;
   __syncthreads();
   if (threadIdx.x < kRow) {
-    if (col == kRowCount) {
-      // the residual count leaves this kernel as two exactly representable floats (low / high 16 bits)
-      // so that the row can go through a float all-reduce (sum) across GPUs unchanged in meaning
-      uint32_t total = 0;
-      for (int i = 0; i < 8; ++i) total += __float_as_uint(sm[i][col]);
-      coeffs[(size_t)k * kRow + kRowCount] = (float)(total & 0xffffu);
-      coeffs[(size_t)k * kRow + kRowCount + 1] = (float)(total >> 16);
-    } else if (col != kRowCount + 1) {
-      float total = 0.f;
-      for (int i = 0; i < 8; ++i) total += sm[i][col];
-      coeffs[(size_t)k * kRow + col] = total;
-    }
+    float total = 0.f;
+    for (int i = 0; i < 8; ++i) total += sm[i][col];
+    parts[((size_t)k * kReduceParts + part) * kRow + col] = total;
+  }
+}
+
+// Stage B: coeffs[k][col] = sum over parts; the residual count (per-row counts are small exact
+// floats, their sum is formed in integers) leaves as two exactly representable floats (low / high
+// 16 bits) so that the row can go through a float all-reduce across GPUs unchanged in meaning.
+__global__ __launch_bounds__(64) void pose_reduce_final_kernel(const float* __restrict__ parts, int kf_count, float* __restrict__ coeffs,
+                                                              const PoseState* __restrict__ states) {
+  const int k = blockIdx.x;
+  if (states != nullptr && states[k].converged) return;
+  const int col = threadIdx.x;
+  if (col >= kRow) return;
+  if (col == kRowCount) {
+    uint32_t total = 0;
+    for (int p = 0; p < kReduceParts; ++p) total += (uint32_t)parts[((size_t)k * kReduceParts + p) * kRow + col];
+    coeffs[(size_t)k * kRow + kRowCount] = (float)(total & 0xffffu);
+    coeffs[(size_t)k * kRow + kRowCount + 1] = (float)(total >> 16);
+  } else if (col != kRowCount + 1) {
+    float total = 0.f;
+    for (int p = 0; p < kReduceParts; ++p) total += parts[((size_t)k * kReduceParts + p) * kRow + col];
+    coeffs[(size_t)k * kRow + col] = total;
   }
 }
 

@@ -88,12 +88,14 @@ int bsh_upload_keyframe_depth(void* ba, void* stream, int id, const uint16_t* de
   BSH_TRY({
     auto& kf = static_cast<DirectBA*>(ba)->keyframes().at(id);
     kf->mutable_depth_buffer().Upload(static_cast<hipStream_t>(stream), depth, static_cast<size_t>(kf->depth_buffer().width()) * 2);
+    static_cast<DirectBA*>(ba)->InvalidateKeyframeCache();
   });
 }
 int bsh_upload_keyframe_normals(void* ba, void* stream, int id, const uint16_t* normals) {
   BSH_TRY({
     auto& kf = static_cast<DirectBA*>(ba)->keyframes().at(id);
     kf->mutable_normals_buffer().Upload(static_cast<hipStream_t>(stream), normals, static_cast<size_t>(kf->normals_buffer().width()) * 2);
+    static_cast<DirectBA*>(ba)->InvalidateKeyframeCache();
   });
 }
 

@@ -181,6 +181,9 @@ DirectBA::DirectBA(int max_surfel_count, float raw_to_float_depth, float baselin
   if (render_window) throw std::invalid_argument("render_window must be null: visualisation is out of scope");
   if (sparse_surfel_cell_size < 1) throw std::invalid_argument("sparse_surfel_cell_size must be >= 1");
   Check(bslam_create(device, &ctx_), "bslam_create");
+  // this class owns every image the derived per-pixel records depend on and invalidates the cache
+  // whenever it changes one of them in place
+  Check(bslam_set_keyframe_cache(ctx_, 1), "bslam_set_keyframe_cache");
   HIP_OR_THROW(hipSetDevice(device));
   // BS/direct_ba.cc:108-125
   cfactor_buffer_.reset(new DeviceBuffer<float>((depth_camera_.height() - 1) / sparse_surfel_cell_size + 1,
@@ -197,6 +200,8 @@ DirectBA::~DirectBA() {
   keyframes_.clear();
   if (ctx_) bslam_destroy(ctx_);
 }
+
+void DirectBA::InvalidateKeyframeCache() { Check(bslam_invalidate_keyframe_cache(ctx_), "bslam_invalidate_keyframe_cache"); }
 
 void DirectBA::SetTextureMode(int mode) { Check(bslam_set_texture_mode(ctx_, mode), "bslam_set_texture_mode"); }
 
@@ -594,6 +599,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       const bslam_buffer2d cf = cfactor_buffer_->ToPod();
       Check(bslam_update_cfactors_from_pcg_delta(ctx_, stream, &cf, L.depth_intrinsics_unknown_start_index + 5, pcg_delta_->address()),
             "bslam_update_cfactors_from_pcg_delta");
+      InvalidateKeyframeCache();
     }
     if (optimize_color_intrinsics) {   // :628-642
       float buf[4];

@@ -184,6 +184,9 @@ class DirectBA {
   // id >= 0 makes runs reproducible.
   void SetPCGGaugeKeyframe(int id) { fixed_gauge_keyframe_ = id; }
   void SetTextureMode(int mode);
+  // Must be called after rewriting the content of a keyframe's depth / normal image or of the
+  // cfactor image in place (the class does it itself for the changes it makes).
+  void InvalidateKeyframeCache();
   void SetTimingsStream(std::ostream* s) { timings_stream_ = s; }   // --save_timings format of BS/direct_ba_alternating.cc:630-688
   void SetAllReduce(bslam_allreduce_fn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
 

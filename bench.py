@@ -76,6 +76,7 @@ def main():
 
     L = badslam_amd.lib()
     ctx = badslam_amd.Context(local_rank)
+    L.bslam_set_keyframe_cache(ctx.handle, 1)   # the bench never rewrites a keyframe image in place
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     dp = dev.depth_params()
     sb, ab = dev.buf(dev.surfels), dev.buf(dev.active)

@@ -158,6 +158,16 @@ int bslam_destroy(bslam_context* ctx);
 /* Texture filtering mode (BSLAM_TEX_*), default BSLAM_TEX_FIXED_POINT_1_8. */
 int bslam_set_texture_mode(bslam_context* ctx, int mode);
 
+/* The library derives one record per keyframe pixel (calibrated depth, pixel normal, raw depth)
+ * from the caller's depth / normal / cfactor images.  By default the records are rebuilt on every
+ * call, because the caller owns those images and may rewrite them in place between calls (the
+ * reference's tests do, BS/test/test_geometry_optimization_geometric_residual.cc:124-139).
+ * enable = 1: the caller promises to call bslam_invalidate_keyframe_cache() after changing the
+ * CONTENT of any keyframe depth / normal image or of the cfactor image in place; records are then
+ * re-used while buffer addresses, pitches, a, raw_to_float_depth and the cell size are unchanged. */
+int bslam_set_keyframe_cache(bslam_context* ctx, int enable);
+int bslam_invalidate_keyframe_cache(bslam_context* ctx);
+
 /* XCD-aware scheduling (default on): surfel granules are visited along a Morton curve of their
  * centroids, one contiguous range per XCD, so that every XCD's L2 only sees the part of each
  * keyframe image its part of the scene projects to.  Results do not depend on it except for the
