@@ -108,6 +108,8 @@ SIGNATURES = {
         C.c_void_p, C.c_void_p, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
     "bslam_optimize_geometry_iteration": (C.c_int, [
         C.c_void_p, C.c_void_p, C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
+    "bslam_optimize_intrinsics": (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _KFS, _CAM, _CAM, _DP, C.c_uint32, _BUF, _CAM, _CAM, P(C.c_float)]),
     "bslam_debug_association": (C.c_int, [
         C.c_void_p, C.c_void_p, _CAM, _DP, _KFS, C.c_uint32, _BUF, C.c_void_p]),
     "bslam_debug_pose_residuals": (C.c_int, [

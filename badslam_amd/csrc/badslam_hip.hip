@@ -9,6 +9,7 @@
 
 #include "context.hpp"
 #include "geometry_kernels.hpp"
+#include "intrinsics_kernels.hpp"
 #include "pcg_kernels.hpp"
 #include "pose_kernels.hpp"
 
@@ -311,7 +312,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->order.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->order.release(); ctx->intr_cells.release();
   ctx->staging.release(); ctx->staging2.release();
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
@@ -674,4 +675,5 @@ int bslam_debug_pose_residuals(
 
 }  // extern "C"
 
+#include "intrinsics_abi.inc"
 #include "pcg_abi.inc"

@@ -76,6 +76,7 @@ struct bslam_context {
   bslam::Slab coeffs;        // float[K][32]
   bslam::Slab pose_state;    // PoseState[K]
   bslam::Slab misc;          // small device scalars
+  bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
   // derived-record cache (bslam_set_keyframe_cache)

@@ -50,6 +50,8 @@ def host_lib():
     L.bsh_estimate_frame_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p]
     L.bsh_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bsh_get_intrinsics.argtypes = [C.c_void_p, f32p, f32p, f32p]
+    L.bsh_set_intrinsics.argtypes = [C.c_void_p, f32p, f32p, C.c_float]
+    L.bsh_get_cfactor.argtypes = [C.c_void_p, C.c_void_p, f32p]
     _host = L
     return L
 
@@ -177,6 +179,16 @@ class DirectBA:
                                                  max_iterations, int(use_pcg), active_keyframe_window_start, active_keyframe_window_end,
                                                  int(increase_ba_iteration_count), pcg_max_inner_iterations, C.byref(it), C.byref(conv)))
         return it.value, bool(conv.value)
+
+    def set_intrinsics(self, color4=None, depth4=None, a=0.0):
+        c = None if color4 is None else _f(np.ascontiguousarray(color4, np.float32))
+        d = None if depth4 is None else _f(np.ascontiguousarray(depth4, np.float32))
+        self._check(self.L.bsh_set_intrinsics(self._ba, c, d, a))
+
+    def cfactor(self, shape):
+        out = np.zeros(shape, np.float32)
+        self._check(self.L.bsh_get_cfactor(self._ba, self.stream, _f(out)))
+        return out
 
     def intrinsics(self):
         c, d, a = np.zeros(4, np.float32), np.zeros(4, np.float32), C.c_float()

@@ -135,6 +135,21 @@ int bsh_bundle_adjustment(void* ba, void* stream, int optimize_depth_intrinsics,
   });
 }
 
+int bsh_set_intrinsics(void* ba_, const float* color4, const float* depth4, float a) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    if (color4) ba->SetColorCamera(PinholeCamera4f(ba->color_camera().width(), ba->color_camera().height(), color4));
+    if (depth4) ba->SetDepthCamera(PinholeCamera4f(ba->depth_camera().width(), ba->depth_camera().height(), depth4));
+    ba->SetA(a);
+  });
+}
+int bsh_get_cfactor(void* ba_, void* stream, float* out) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    ba->cfactor_buffer().Download(static_cast<hipStream_t>(stream), out, static_cast<size_t>(ba->cfactor_buffer().width()) * sizeof(float));
+  });
+}
+
 int bsh_get_intrinsics(void* ba_, float* color4, float* depth4, float* a) {
   BSH_TRY({
     DirectBA* ba = static_cast<DirectBA*>(ba_);

@@ -341,8 +341,6 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
                                            std::function<bool(int)> progress_function) {
   if (converged) *converged = false;
   if (num_iterations_done) *num_iterations_done = 0;
-  if (optimize_depth_intrinsics || optimize_color_intrinsics)
-    throw std::invalid_argument("intrinsics optimisation in the alternating scheme (OptimizeIntrinsicsCUDA) is not built yet; use use_pcg = true");
   const auto t_start = std::chrono::steady_clock::now();
 
   Lock();
@@ -355,12 +353,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
 
   HIP_OR_THROW(hipMemsetAsync(active_surfels_->address(), 0, surfels_size_ * sizeof(u8), stream));   // :338
 
-  const bslam_camera4f color_cam = color_camera_.pod(), depth_cam = depth_camera_.pod();
   const bslam_buffer2d surfels = surfels_->ToPod(), active = active_surfels_->ToPod();
 
   for (int iteration = 0; iteration < max_iterations; ++iteration) {
     if (progress_function && !progress_function(iteration)) break;
     if (num_iterations_done) ++*num_iterations_done;
+    const bslam_camera4f color_cam = color_camera_.pod(), depth_cam = depth_camera_.pod();   // intrinsics may change per iteration
 
     if (fixed_active_keyframe_set) {   // :352-371
       Lock();
@@ -439,6 +437,26 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         Unlock();
       }
       HIP_OR_THROW(hipEventRecord(ev_[5], stream));
+    }
+
+    // --- INTRINSICS OPTIMIZATION (:579-624) ---
+    if (optimize_depth_intrinsics || optimize_color_intrinsics) {
+      std::vector<bslam_keyframe_view> all_views = KeyframeViews();   // poses may have changed above
+      bslam_camera4f out_color = color_cam, out_depth = depth_cam;
+      float out_a = a_;
+      Check(bslam_optimize_intrinsics(ctx_, stream, optimize_depth_intrinsics, optimize_color_intrinsics, static_cast<int>(all_views.size()),
+                                      all_views.data(), &color_cam, &depth_cam, &dp, surfels_size_, &surfels, &out_color, &out_depth, &out_a),
+            "bslam_optimize_intrinsics");
+      if (surfels_size_ > 0) {
+        Lock();
+        if (optimize_color_intrinsics) { const float p[4] = {out_color.fx, out_color.fy, out_color.cx, out_color.cy}; color_camera_ = PinholeCamera4f(out_color.width, out_color.height, p); }
+        if (optimize_depth_intrinsics) {
+          const float p[4] = {out_depth.fx, out_depth.fy, out_depth.cx, out_depth.cy};
+          depth_camera_ = PinholeCamera4f(out_depth.width, out_depth.height, p);
+          a_ = out_a;
+        }
+        Unlock();
+      }
     }
 
     // --- TIMING (:626-689), same line format as --save_timings ---

@@ -9,8 +9,7 @@
 //
 // Not on the hot path and therefore absent ("out of scope" / "next" rows): surfel
 // creation / merge / deletion / compaction (do_surfel_updates must be false, surfels are
-// uploaded with SetSurfels), keyframe merging, visualisation, the alternating-scheme intrinsics
-// step (OptimizeIntrinsicsCUDA).
+// uploaded with SetSurfels), keyframe merging, visualisation.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -198,6 +197,8 @@ class DirectBA {
   bslam_depth_params depth_params() const;
   float a() const { return a_; }
   void SetA(float a) { a_ = a; }
+  void SetDepthCamera(const PinholeCamera4f& camera) { depth_camera_ = camera; }   // BS/direct_ba.h (used by the intrinsics tests)
+  void SetColorCamera(const PinholeCamera4f& camera) { color_camera_ = camera; }
   const DeviceBuffer<float>& cfactor_buffer() const { return *cfactor_buffer_; }
   u32 surfels_size() const { return surfels_size_; }
   u32 surfel_count() const { return surfel_count_; }

@@ -285,6 +285,20 @@ int bslam_optimize_geometry_iteration(
     uint32_t surfels_size, const bslam_buffer2d* surfels,
     const bslam_buffer2d* active_surfels);
 
+/* Replaces OptimizeIntrinsicsCUDA (BS/kernels.h:246-260, BS/kernel_opt_intrinsics.cc:38-283): one
+ * Gauss-Newton step on the depth intrinsics (1/fx, 1/fy, -cx/fx, -cy/fy, a, then the per-cell
+ * cfactors through the Schur complement, prior 100 a^2) and / or the colour intrinsics.
+ * depth_params->cfactor_buffer (device) is updated in place; *a is in/out (the value in
+ * depth_params->a is ignored in favour of *a); the out cameras are HOST structs. */
+int bslam_optimize_intrinsics(
+    bslam_context* ctx, void* stream,
+    int optimize_depth_intrinsics, int optimize_color_intrinsics,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    bslam_camera4f* out_color_camera, bslam_camera4f* out_depth_camera, float* a);
+
 /* Per-surfel association probe (test / debugging aid; the reference has no such
  * export, the tests need it to check the bit-exact parity target of
  * SURVEY.md 8(a5)): for one keyframe writes out_pixel[i] = py * width + px of the

@@ -125,6 +125,16 @@ void bso_update_surfels_from_pcg_delta(uint32_t surfels_size, const bslam_buffer
 void bso_update_cfactors_from_pcg_delta(const bslam_buffer2d* cfactor_buffer,
                                         uint32_t cfactor_unknown_start_index, const float* pcg_delta);
 
+/* OptimizeIntrinsicsCUDA (BS/kernel_opt_intrinsics.cc:38-283): one Gauss-Newton step on the depth
+ * intrinsics (1/fx, 1/fy, -cx/fx, -cy/fy, a; then the cfactor cells through the Schur complement)
+ * and/or the colour intrinsics.  Updates dp->cfactor_buffer in place, *a, and the out cameras. */
+void bso_optimize_intrinsics(
+    int optimize_depth_intrinsics, int optimize_color_intrinsics,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    bslam_camera4f* out_color_camera, bslam_camera4f* out_depth_camera, float* a, int tex_mode);
+
 /* ---- scene construction (restates the producers either side of the path so the
  * reference's known-answer scenes can be rebuilt; "next" rows of SURVEY.md 8f) ---- */
 

@@ -1,0 +1,152 @@
+/*
+ * bso_intrinsics.c -- ORACLE (test infrastructure only; see bslam_oracle.h).
+ *
+ * Serial restatement of OptimizeIntrinsicsCUDA (BS/kernel_opt_intrinsics.cc:38-283) and its three
+ * kernels (BS/kernel_opt_intrinsics.cu:46-448); BS/ = /root/reference/applications/badslam/src/badslam/.
+ * Block reductions + atomics become fp32 additions in (keyframe, surfel) / cell order.
+ */
+#include <math.h>
+#include <stdlib.h>
+
+#include "bslam_oracle.h"
+#include "bso_math.h"
+
+#define K_A_ROWS 5
+
+/* AccumulateGaussNewtonHAndB<size> BS/gauss_newton.cuh:47-95 for a generic size */
+static void accumulate_n(int n, float raw, float w, const float* J, float* H, float* b) {
+  int idx = 0;
+  for (int row = 0; row < n; ++row)
+    for (int col = row; col < n; ++col) { H[idx] += w * J[row] * J[col]; ++idx; }
+  const float wr = w * raw;
+  for (int i = 0; i < n; ++i) b[i] += wr * J[i];
+}
+
+void bso_optimize_intrinsics(
+    int optimize_depth_intrinsics, int optimize_color_intrinsics,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    uint32_t surfels_size, const bslam_buffer2d* surfels,
+    bslam_camera4f* out_color_camera, bslam_camera4f* out_depth_camera, float* a, int tex_mode) {
+  if (surfels_size == 0) return;
+  const bso_unprojector unproj = bso_make_unprojector(depth_camera);
+  const bso_depth_to_color d2c = bso_make_depth_to_color(depth_camera, color_camera);
+  const int cw = dp->cfactor_buffer.width;
+  const int cells = ((depth_camera->width - 1) / dp->sparse_surfel_cell_size + 1) * ((depth_camera->height - 1) / dp->sparse_surfel_cell_size + 1);
+  float A[15] = {0}, b1[K_A_ROWS] = {0};
+  float color_H[10] = {0}, color_b[4] = {0};
+  float* B = (float*)calloc((size_t)K_A_ROWS * cells, sizeof(float));
+  float* D = (float*)calloc((size_t)cells, sizeof(float));
+  float* b2 = (float*)calloc((size_t)cells, sizeof(float));
+  uint32_t* obs = (uint32_t*)calloc((size_t)cells, sizeof(uint32_t));
+
+  for (int k = 0; k < keyframe_count; ++k) {                       /* :80-108 */
+    const bslam_keyframe_view* kf = &keyframes[k];
+    for (uint32_t i = 0; i < surfels_size; ++i) {                   /* kernel :46-217 */
+      float dj[K_A_ROWS + 1] = {0, 0, 0, 0, 0, 0};
+      float raw_depth = 0;
+      float j1[4] = {0, 0, 0, 0}, j2[4] = {0, 0, 0, 0};
+      float r1 = 0, r2 = 0;
+      int cell = -1;
+      bso_projection r;
+      if (bso_surfel_projects_to_associated_pixel(i, surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r)) {
+        const float nx = bso_unproj_nx(&unproj, r.px), ny = bso_unproj_ny(&unproj, r.py);
+        if (optimize_depth_intrinsics) {
+          const int sparse_px = r.px / dp->sparse_surfel_cell_size, sparse_py = r.py / dp->sparse_surfel_cell_size;
+          const float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
+          const float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
+          const float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+          const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+          if (fabsf(corrected_inv_depth) > 1e-4f) {
+            const bso_f3 ln = bso_rotate34(&kf->frame_T_global, r.surfel_normal);
+            const float dot = bso_dot(bso_make3(nx, ny, 1), ln);
+            const float inv_stddev = bso_depth_inv_stddev(nx, ny, r.calibrated_depth, ln, dp->baseline_fx);
+            const float jac_base = inv_stddev * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
+            const float* m = kf->frame_T_global.m;
+            dj[2] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[0], m[1], m[2]));
+            dj[3] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[4], m[5], m[6]));
+            dj[0] = r.px * dj[2];
+            dj[1] = r.py * dj[3];
+            dj[4] = cfactor * raw_inv_depth * jac_base;
+            dj[5] = -jac_base;
+            const bso_f3 lu = bso_make3(r.calibrated_depth * nx, r.calibrated_depth * ny, r.calibrated_depth);
+            raw_depth = inv_stddev * bso_dot(ln, bso_sub(lu, r.local_position));
+            cell = sparse_px + sparse_py * cw;
+          }
+        }
+        if (optimize_color_intrinsics) {
+          bso_f2 color_pxy;
+          if (bso_depth_to_color_pxy(r.pxy, &d2c, &color_pxy)) {
+            bso_f2 t1, t2;
+            bso_tangent_projections(r.global_position, r.surfel_normal, BSO_AT(float, surfels, BSLAM_SURFEL_RADIUS_SQUARED, i),
+                                    &kf->frame_T_global, color_camera->fx, color_camera->fy, color_camera->cx, color_camera->cy, &t1, &t2);
+            float gx1, gy1, gx2, gy2;
+            bso_descriptor_jacobian_wrt_projected_position(&kf->color, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+            j1[0] = gx1 * nx; j1[1] = gy1 * ny; j1[2] = gx1; j1[3] = gy1;
+            j2[0] = gx2 * nx; j2[1] = gy2 * ny; j2[2] = gx2; j2[3] = gy2;
+            bso_raw_descriptor_residual(&kf->color, tex_mode, color_pxy, t1, t2, BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR1, i),
+                                        BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR2, i), &r1, &r2);
+          }
+        }
+      }
+      if (optimize_depth_intrinsics && cell >= 0) {                 /* :170-196 */
+        const float w = bso_depth_weight(raw_depth);
+        accumulate_n(K_A_ROWS, raw_depth, w, dj, A, b1);
+        for (int q = 0; q < K_A_ROWS; ++q) B[(size_t)q * cells + cell] += w * dj[q] * dj[K_A_ROWS];
+        D[cell] += w * dj[K_A_ROWS] * dj[K_A_ROWS];
+        b2[cell] += w * raw_depth * dj[K_A_ROWS];
+        obs[cell] += 1;
+      }
+      if (optimize_color_intrinsics) {                              /* :198-216: "valid" = residual != 0 */
+        if (r1 != 0) accumulate_n(4, r1, bso_desc_weight(r1), j1, color_H, color_b);
+        if (r2 != 0) accumulate_n(4, r2, bso_desc_weight(r2), j2, color_H, color_b);
+      }
+    }
+  }
+
+  if (optimize_depth_intrinsics) {
+    /* ComputeIntrinsicsIntermediateMatricesCUDAKernel :265-340 */
+    for (int p = 0; p < cells; ++p) {
+      const float D_inverse = 1.0f / D[p];
+      if (!(D_inverse < 1e12f)) { D[p] = NAN; continue; }
+      const float D_inv_b2 = D_inverse * b2[p];
+      D[p] = D_inv_b2;
+      int idx = 0;
+      for (int row = 0; row < K_A_ROWS; ++row)
+        for (int col = row; col < K_A_ROWS; ++col) { A[idx] += -1.f * (B[(size_t)row * cells + p] * D_inverse * B[(size_t)col * cells + p]); ++idx; }
+      for (int row = 0; row < K_A_ROWS; ++row) b1[row] += -1.f * (B[(size_t)row * cells + p] * D_inv_b2);
+      for (int row = 0; row < K_A_ROWS; ++row) B[(size_t)row * cells + p] = D_inverse * B[(size_t)row * cells + p];
+    }
+    /* host solve BS/kernel_opt_intrinsics.cc:129-186 */
+    const float kAPriorWeight = 10;
+    A[14] += kAPriorWeight * kAPriorWeight;            /* cpu_matrix(4, 4) */
+    b1[4] += kAPriorWeight * kAPriorWeight * (*a);
+    float x1[K_A_ROWS];
+    bso_solve_ldlt_upper(K_A_ROWS, A, b1, x1);
+    const float new_fx = 1.0f / (unproj.fx_inv - x1[0]);
+    const float new_fy = 1.0f / (unproj.fy_inv - x1[1]);
+    const float new_cx = -(new_fx * (unproj.cx_inv - x1[2])) + 0.5f;
+    const float new_cy = -(new_fy * (unproj.cy_inv - x1[3])) + 0.5f;
+    out_depth_camera->fx = new_fx; out_depth_camera->fy = new_fy; out_depth_camera->cx = new_cx; out_depth_camera->cy = new_cy;
+    out_depth_camera->width = depth_camera->width; out_depth_camera->height = depth_camera->height;
+    *a -= x1[4];
+    /* SolveForPixelIntrinsicsUpdateCUDAKernel :374-420 */
+    for (int p = 0; p < cells; ++p) {
+      float offset = D[p];
+      if (isnan(offset)) offset = 0;
+      else for (int row = 0; row < K_A_ROWS; ++row) offset -= B[(size_t)row * cells + p] * x1[row];
+      const int y = p / cw, x = p - y * cw;
+      float cfactor = BSO_AT(float, &dp->cfactor_buffer, y, x) - offset;
+      if (obs[p] == 0) cfactor = 0;
+      BSO_AT(float, &dp->cfactor_buffer, y, x) = cfactor;
+    }
+  }
+  if (optimize_color_intrinsics) {                                    /* :251-280 */
+    float x[4];
+    bso_solve_ldlt_upper(4, color_H, color_b, x);
+    out_color_camera->fx = color_camera->fx - x[0]; out_color_camera->fy = color_camera->fy - x[1];
+    out_color_camera->cx = color_camera->cx - x[2]; out_color_camera->cy = color_camera->cy - x[3];
+    out_color_camera->width = color_camera->width; out_color_camera->height = color_camera->height;
+  }
+  free(B); free(D); free(b2); free(obs);
+}

@@ -67,6 +67,7 @@ def lib():
         "bso_pcg_step3": (None, [P(abi.PCGLayout), P(abi.PCGVectors)]),
         "bso_update_surfels_from_pcg_delta": (None, [C.c_uint32, _BUF, C.c_int, C.c_uint32, f32p]),
         "bso_update_cfactors_from_pcg_delta": (None, [_BUF, C.c_uint32, f32p]),
+        "bso_optimize_intrinsics": (None, [C.c_int, C.c_int, C.c_int, _KFS, _CAM, _CAM, _DP, C.c_uint32, _BUF, _CAM, _CAM, f32p, C.c_int]),
         "bso_compute_brightness": (None, [C.c_int, C.c_int, C.c_void_p, _BUF]),
         "bso_preprocess_depth": (None, [_CAM, _DP, _BUF, _BUF, _BUF, _BUF, f32p, f32p]),
         "bso_create_surfels_for_keyframe": (C.c_uint32, [_CAM, _CAM, _DP, _KFS, P(abi.SE3f), u32p, C.c_uint32, _BUF, C.c_int]),
@@ -302,6 +303,20 @@ class HostScene:
             int(self.use_depth_residuals), int(self.use_descriptor_residuals), C.byref(self.color_camera),
             C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs, self.surfels_size, C.byref(sb), C.byref(ab),
             self.tex_mode)
+
+    def optimize_intrinsics(self, optimize_depth, optimize_color):
+        """One OptimizeIntrinsicsCUDA step on the host state (cameras, a, cfactor updated in place)."""
+        dp, sb, kfs = self.depth_params(), self.surfel_buf(), self.keyframe_views()
+        out_c, out_d = abi.Camera4f(), abi.Camera4f()
+        a = C.c_float(self.a)
+        lib().bso_optimize_intrinsics(int(optimize_depth), int(optimize_color), len(self.keyframes), kfs, C.byref(self.color_camera),
+                                      C.byref(self.depth_camera), C.byref(dp), self.surfels_size, C.byref(sb), C.byref(out_c), C.byref(out_d),
+                                      C.byref(a), self.tex_mode)
+        if optimize_color:
+            self.color_camera = out_c
+        if optimize_depth:
+            self.depth_camera = out_d
+            self.a = a.value
 
     # --- upload
     def to_device(self, device="cuda:0"):

@@ -97,6 +97,18 @@ class Hip:
             max_iterations, poses, iters, conv, cb, None))
         return [poses[k] for k in range(K)], list(iters), list(conv)
 
+    def optimize_intrinsics(self, optimize_depth, optimize_color):
+        """bslam_optimize_intrinsics on the device scene; returns (color_camera, depth_camera, a)."""
+        dp, sb = self._common()
+        kfs = self.d.keyframe_views()
+        out_c, out_d = abi.Camera4f(), abi.Camera4f()
+        a = C.c_float(self.h.a)
+        badslam_amd.check(self.L.bslam_optimize_intrinsics(
+            self.ctx.handle, stream_ptr(), int(optimize_depth), int(optimize_color), len(self.h.keyframes), kfs, C.byref(self.h.color_camera),
+            C.byref(self.h.depth_camera), C.byref(dp), self.d.surfels_size, C.byref(sb), C.byref(out_c), C.byref(out_d), C.byref(a)))
+        self.torch.cuda.synchronize()
+        return out_c, out_d, a.value
+
     def update_activation(self):
         dp, sb = self._common()
         ab, kfs = self.d.active_buf(), self.d.keyframe_views()

@@ -217,3 +217,40 @@ def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, ma
         kf = scene.add_keyframe_from_images(depth, rgb, T)
         scene.create_surfels_for_keyframe(kf)
     return scene
+
+
+def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False):
+    """Scene of {Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-560): 20 random planes rendered
+    from `num_keyframes` poses global_T_0 * exp(xi) (:286-296), undistorted depth, cell size 2; surfels
+    are created from every keyframe with the true camera.  (The reference filters new surfels by
+    observation count, :516; creation is unfiltered here.)"""
+    rng = np.random.default_rng(seed)
+    cam = reference_test_camera(width, height)
+    raw_to_float_depth = np.float32(1.0 / 1000)
+    scene = bso.HostScene(cam, cam, float(raw_to_float_depth), 40.0, cell, max_surfels,
+                          use_depth_residuals=True, use_descriptor_residuals=use_descriptor_residuals)
+    planes = random_planes(rng, 20)
+    T0 = bso.se3_exp([0.01, 0.02, 0.03, 0.004, 0.005, 0.006])
+    dxg, dyg = unproject_dirs(cam, width, height)
+    d = np.stack([dxg, dyg, np.ones_like(dxg)], axis=-1).astype(np.float64)
+    for k in range(num_keyframes):
+        xi = np.concatenate([3.0 * (rng.integers(0, 200, 3) / 200.0 - 0.5), 3.5 * ((rng.integers(0, 200, 3) - 100) / 500.0)]).astype(np.float32)
+        T = bso.se3_mul(T0, bso.se3_exp(xi))
+        M = np.array(list(bso.se3_matrix3x4(T).m), np.float64).reshape(3, 4)
+        dg = d @ M[:, :3].T
+        o = M[:, 3]
+        best = np.zeros((height, width))
+        for n in planes:   # RenderPlanes (:134-160): nearest positive ray parameter, no facing test
+            n64 = n.astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                z = -(2.5 + o @ n64) / (dg @ n64)
+            upd = (z > 0) & ((best == 0) | (z < best))
+            best = np.where(upd, z, best)
+        depth = np.full((height, width), 65535, np.uint16)
+        inner = np.minimum(65535, best[1:-1, 1:-1] / float(raw_to_float_depth) + 0.5)
+        depth[1:-1, 1:-1] = np.where(best[1:-1, 1:-1] == 0, 65535, inner).astype(np.uint16)
+        rgb = np.zeros((height, width, 3), np.uint8)
+        kf = scene.add_keyframe_from_images(depth, rgb, T)
+        scene.create_surfels_for_keyframe(kf)
+    return scene

@@ -88,3 +88,26 @@ def test_pcg_geometry_optimization_with_geometric_residual(oracle):
             ok = True
             break
     assert ok, ((err > 1e-4).sum(), err.size)
+
+
+def distorted_camera(cam, scale=1.0):
+    """BS/test/test_intrinsics_optimization_geometric_residual.cc:398: {0.5h + 0.5, 0.45h - 0.6, cx + 1.23, cy - 2.17}
+    (fy = 0.9 x the true one), offsets scaled with the image size."""
+    return bso.make_camera(cam.fx + 0.5 * scale, 0.9 * cam.fy - 0.6 * scale, cam.cx + 1.23 * scale, cam.cy - 2.17 * scale, cam.width, cam.height)
+
+
+def test_intrinsics_optimization_with_geometric_residual_reduced(oracle):
+    """Optimization.AlternatingIntrinsicsOptimizationWithGeometricResidual
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-553) on the oracle at reduced
+    size (160x120, 12 keyframes; the full 640x480 x 36 keyframes x 1000 passes version runs through
+    the HIP path in tests/test_gpu_direct_ba.py): only the depth intrinsics are optimised, starting
+    from a camera that is off by (+0.5, -10 % - 0.6, +1.23, -2.17) px; bar: 1e-3 px on fx, fy, cx, cy."""
+    w, h = 160, 120
+    scene = scenes.intrinsics_scene(12, seed=0, width=w, height=h, cell=2, max_surfels=200000)
+    true = scene.depth_camera
+    scene.depth_camera = distorted_camera(true, w / 640.0)
+    for _ in range(20):
+        scene.optimize_intrinsics(True, False)
+    est = scene.depth_camera
+    err = [abs(est.fx - true.fx), abs(est.fy - true.fy), abs(est.cx - true.cx), abs(est.cy - true.cy)]
+    assert max(err) < 1e-3, err
