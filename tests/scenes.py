@@ -122,6 +122,53 @@ def geometry_geometric_scene(seed=0, width=W, height=H, max_surfels=1000 * 1000)
     return scene, kf, new_depth
 
 
+def geometry_photometric_scene(width=W, height=H, max_surfels=1000 * 1000, seed=0, tex_mode=abi.TEX_FIXED_POINT_1_8):
+    """{Alternating,PCG}GeometryOptimizationWithPhotometricResidual
+    (BS/test/test_geometry_optimization_photometric_residual.cc:128-268): two keyframes 100 px
+    apart looking at a fronto-parallel plane at 2 m; surfels are created from keyframe 1, whose
+    depth carries up to 1 cm of noise.  Returns (scene, kf0, kf1, expected_z)."""
+    rng = np.random.default_rng(seed)
+    cam = reference_test_camera(width, height)
+    raw_to_float_depth = np.float32(1.0 / 5000)
+    scene = bso.HostScene(cam, cam, float(raw_to_float_depth), 40.0, 1, max_surfels,
+                          use_depth_residuals=False, use_descriptor_residuals=True, tex_mode=tex_mode)
+    off = 100 * width // W          # kFrameOffsetPx, scaled with reduced-size images
+    kdepth = np.float32(2.0)
+    d0 = np.full((height, width), np.uint16(kdepth / raw_to_float_depth + np.float32(0.5)), np.uint16)
+    d0[:, :off] = 65535
+    d0[0, :] = d0[-1, :] = 65535
+    d0[:, -1] = 65535
+    xs = np.arange(width, dtype=np.float32)[None, :]
+    ys = np.arange(height, dtype=np.float32)[:, None]
+    lum = (np.float32(255 / 2.0) * (np.float32(1) + np.sin(np.float32(0.15) * xs + np.float32(0.5) * np.sin(np.float32(0.25) * ys)))).astype(np.float32)
+    c0 = lum.astype(np.int32).astype(np.uint8)     # + rand() % 1 == 0 (:188)
+    rgb0 = np.repeat(c0[:, :, None], 3, axis=2)
+    T0 = bso.se3_exp([0.1, 0.2, 0.3, 0.4, 0.5, 0.6])
+    kf0 = scene.add_keyframe_from_images(d0, rgb0, T0)
+    kf0.normals[:, :] = 0                            # ImageSpaceNormalToU16(0, 0) (:206-213)
+    # keyframe 1: the same content shifted by `off` px, depth + noise (:217-227); u16 wrap-around of the
+    # column that reads keyframe 0's invalid right border is kept.
+    r = rng.integers(0, 100, size=(height, width)).astype(np.float32)
+    d1 = d0.copy()
+    c1 = c0.copy()
+    shifted = d0[:, off:].astype(np.float32) + (np.float32(0.0001) * r[:, :width - off]) / raw_to_float_depth
+    d1[:, :width - off] = shifted.astype(np.uint32).astype(np.uint16)
+    c1[:, :width - off] = c0[:, off:]
+    d1[:, 0] = 65535
+    d1[0, :] = d1[-1, :] = 65535
+    d1[:, width - off:] = 65535
+    c1[:, 0] = c0[:, 0]
+    c1[0, :], c1[-1, :] = c0[0, :], c0[-1, :]
+    rgb1 = np.repeat(c1[:, :, None], 3, axis=2)
+    rel = bso.se3_identity()
+    rel.t[0] = float(kdepth * np.float32(off) / np.float32(cam.fx))
+    T1 = bso.se3_mul(T0, rel)
+    kf1 = scene.add_keyframe_from_images(d1, rgb1, T1)
+    kf1.normals[:, :] = 0
+    scene.create_surfels_for_keyframe(kf1)
+    return scene, kf0, kf1, float(kdepth)
+
+
 def offsets_13(translation_offset, rotation_offset):
     """The 13 start offsets of BS/test/test_pose_optimization_geometric_residual.cc:136-152."""
     out = [bso.se3_identity()]
@@ -219,17 +266,21 @@ def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, ma
     return scene
 
 
-def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False):
+def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False,
+                    photometric=False):
     """Scene of {Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual
     (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-560): 20 random planes rendered
     from `num_keyframes` poses global_T_0 * exp(xi) (:286-296), undistorted depth, cell size 2; surfels
     are created from every keyframe with the true camera.  (The reference filters new surfels by
-    observation count, :516; creation is unfiltered here.)"""
+    observation count, :516; creation is unfiltered here.)
+    photometric=True gives the scene of {Alternating,PCG}IntrinsicsOptimizationWithPhotometricResidual
+    (BS/test/test_intrinsics_optimization_photometric_residual.cc:25-160): border pixels keep their depth,
+    the colour is a world-space sinusoid texture (:50-53), descriptor residuals only."""
     rng = np.random.default_rng(seed)
     cam = reference_test_camera(width, height)
     raw_to_float_depth = np.float32(1.0 / 1000)
     scene = bso.HostScene(cam, cam, float(raw_to_float_depth), 40.0, cell, max_surfels,
-                          use_depth_residuals=True, use_descriptor_residuals=use_descriptor_residuals)
+                          use_depth_residuals=not photometric, use_descriptor_residuals=use_descriptor_residuals or photometric)
     planes = random_planes(rng, 20)
     T0 = bso.se3_exp([0.01, 0.02, 0.03, 0.004, 0.005, 0.006])
     dxg, dyg = unproject_dirs(cam, width, height)
@@ -251,6 +302,16 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
         inner = np.minimum(65535, best[1:-1, 1:-1] / float(raw_to_float_depth) + 0.5)
         depth[1:-1, 1:-1] = np.where(best[1:-1, 1:-1] == 0, 65535, inner).astype(np.uint16)
         rgb = np.zeros((height, width, 3), np.uint8)
+        if photometric:
+            depth = np.where(best == 0, 65535, np.minimum(65535, best / float(raw_to_float_depth) + 0.5)).astype(np.uint16)
+            g = (o[None, None, :] + dg * best[..., None]).astype(np.float32)
+            f = np.float32(200)
+
+            def chan(p, q):
+                v = np.float32(255 / 2.0) * (np.float32(1) + np.sin(np.float32(0.15) * f * p + np.float32(0.5) * np.sin(np.float32(0.25) * f * q)))
+                return v.astype(np.int32).astype(np.uint8)
+            col = np.stack([chan(g[..., 0], g[..., 1]), chan(g[..., 1], g[..., 2]), chan(g[..., 2], g[..., 0])], axis=-1)
+            rgb = np.where((best > 0)[..., None], col, 0).astype(np.uint8)
         kf = scene.add_keyframe_from_images(depth, rgb, T)
         scene.create_surfels_for_keyframe(kf)
     return scene
