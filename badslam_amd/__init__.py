@@ -9,7 +9,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbadslam_hip.so")
+# BSLAM_HIP_LIB points tools/variants.py's tuning builds at an alternative kernel library
+LIB_PATH = os.environ.get("BSLAM_HIP_LIB") or os.path.join(_HERE, "libbadslam_hip.so")
 
 _lib = None
 

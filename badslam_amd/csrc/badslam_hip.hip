@@ -123,6 +123,14 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   const size_t rec_per_kf = (size_t)c.width * c.height;
   if ((rc = ctx->records.reserve(table.size() * rec_per_kf * sizeof(uint2)))) return rc;
   for (size_t k = 0; k < table.size(); ++k) table[k].records = (const uint2*)ctx->records.ptr + k * rec_per_kf;
+  const bool with_color = !table.empty() && table[0].color != nullptr;
+  const size_t quads_per_kf = (size_t)(c.color_width + 1) * (size_t)(c.color_height + 1);
+  if (with_color) {
+    if ((rc = ctx->quads.reserve(table.size() * quads_per_kf * sizeof(uint32_t)))) return rc;
+    for (size_t k = 0; k < table.size(); ++k) table[k].quads = (const uint32_t*)ctx->quads.ptr + k * quads_per_kf;
+  } else {
+    for (size_t k = 0; k < table.size(); ++k) table[k].quads = nullptr;
+  }
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));
   std::memcpy(ctx->staging.ptr, table.data(), bytes);
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, ctx->staging.ptr, bytes, hipMemcpyHostToDevice, stream));
@@ -133,7 +141,11 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   if (ctx->keyframe_cache) {
     std::vector<uint64_t> sig;
     sig.reserve(table.size() * 4 + 8);
-    for (const KfDev& kf : table) { sig.push_back((uint64_t)kf.depth); sig.push_back((uint64_t)kf.normals); sig.push_back(((uint64_t)kf.depth_pitch << 32) | kf.normals_pitch); }
+    for (const KfDev& kf : table) {
+      sig.push_back((uint64_t)kf.depth); sig.push_back((uint64_t)kf.normals); sig.push_back(((uint64_t)kf.depth_pitch << 32) | kf.normals_pitch);
+      sig.push_back((uint64_t)kf.color); sig.push_back((uint64_t)kf.color_pitch);
+    }
+    sig.push_back(with_color ? (uint64_t)ctx->quads.ptr : 0); sig.push_back(((uint64_t)c.color_width << 32) | (uint32_t)c.color_height);
     uint32_t fa, fr; std::memcpy(&fa, &c.a, 4); std::memcpy(&fr, &c.raw_to_float_depth, 4);
     sig.push_back((uint64_t)c.cfactor); sig.push_back(((uint64_t)c.cfactor_pitch << 32) | (uint32_t)c.cell);
     sig.push_back(((uint64_t)fa << 32) | fr); sig.push_back(((uint64_t)c.width << 32) | (uint32_t)c.height);
@@ -143,6 +155,11 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   if (rebuild && !table.empty() && table[0].depth != nullptr) {
     hipLaunchKernelGGL(build_records_kernel, dim3((unsigned)((c.width + 255) / 256), (unsigned)c.height, (unsigned)table.size()), dim3(256), 0, stream,
                        c, (const KfDev*)ctx->kf_table.ptr, (uint2*)ctx->records.ptr);
+    BSLAM_HIP_TRY(hipGetLastError());
+  }
+  if (rebuild && with_color) {
+    hipLaunchKernelGGL(build_quads_kernel, dim3((unsigned)((c.color_width + 1 + 255) / 256), (unsigned)(c.color_height + 1), (unsigned)table.size()), dim3(256), 0, stream,
+                       c, (const KfDev*)ctx->kf_table.ptr, (uint32_t*)ctx->quads.ptr);
     BSLAM_HIP_TRY(hipGetLastError());
   }
   return BSLAM_OK;
@@ -248,7 +265,8 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
                                   int* tiles_out) {
   Schedule sc;
-  int rc = make_schedule(ctx, stream, surfels, surfels_size, kPoseR, &sc);
+  const int R = use_desc ? kPoseRDesc : kPoseRGeo;
+  int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &sc);
   if (rc) return rc;
   const int tiles = (int)sc.slots;
   *tiles_out = tiles;
@@ -266,9 +284,9 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   float* partials = (float*)ctx->partials.ptr;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   }
   BSLAM_HIP_TRY(hipGetLastError());
   float* parts = partials + partial_floats;
@@ -312,7 +330,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->order.release(); ctx->intr_cells.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->order.release(); ctx->intr_cells.release();
   ctx->staging.release(); ctx->staging2.release();
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }

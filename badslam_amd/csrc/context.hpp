@@ -72,6 +72,7 @@ struct bslam_context {
   int cu_count = 256;
   bslam::Slab kf_table;      // KfDev[K]
   bslam::Slab records;       // uint2[K][h][w] derived pixel records
+  bslam::Slab quads;         // uint32[K][ch+1][cw+1] derived luma quads (only when colour images are given)
   bslam::Slab partials;      // float[tiles][K][32]
   bslam::Slab coeffs;        // float[K][32]
   bslam::Slab pose_state;    // PoseState[K]

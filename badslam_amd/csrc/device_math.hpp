@@ -74,6 +74,10 @@ struct KfDev {
   // derived per-pixel records {f32 calibrated depth, u16 pixel normal, u16 raw depth}, row pitch in
   // records = image width (library-owned, rebuilt by build_records_kernel)
   const uint2* records;
+  // derived luma quads: quads[(j + 1) * (color_width + 1) + (i + 1)] packs the 2x2 texel footprint
+  // {L(i,j), L(i+1,j), L(i,j+1), L(i+1,j+1)} (clamp addressing, i in [-1, w-1], j in [-1, h-1]) so that a
+  // bilinear sample is ONE 4-byte gather instead of four byte gathers (library-owned, build_quads_kernel)
+  const uint32_t* quads;
   M34 frame_T_global;
   float global_R_frame[9];
   int activation;
@@ -165,31 +169,61 @@ __device__ __forceinline__ int f2i(float v) { return (int)v; }
 // bilinear filtering of the reference's texture (BS/keyframe.cc:67-73) are ALU code over plain
 // global loads of the luma byte (.w of the uchar4 pixel).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float texel_w(const uint8_t* color, uint32_t pitch, int w, int h, int ix, int iy) {
-  ix = max(0, min(ix, w - 1));
-  iy = max(0, min(iy, h - 1));
-  return (float)color[(size_t)iy * pitch + 4 * (size_t)ix + 3] * (1.0f / 255.0f);
+// Loads through the global address space: pointers read out of the keyframe table are generic
+// pointers to the compiler, which would otherwise emit flat_load.
+template <class T>
+__device__ __forceinline__ T gload(const T* p) {
+  return *(const __attribute__((address_space(1))) T*)(p);
 }
 
-__device__ __forceinline__ float tex_w(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y, int mode) {
+__device__ __forceinline__ uint2 gload_u2(const uint2* p) {   // one 8-byte load
+  const unsigned long long v = gload((const unsigned long long*)p);
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+struct LumaQuad { float tl, tr, bl, br; };   // texels (i,j), (i+1,j), (i,j+1), (i+1,j+1) in [0,1]
+
+__device__ __forceinline__ LumaQuad unpack_quad(uint32_t q) {
+  LumaQuad r;
+  r.tl = (float)(q & 0xffu) * (1.0f / 255.0f);
+  r.tr = (float)((q >> 8) & 0xffu) * (1.0f / 255.0f);
+  r.bl = (float)((q >> 16) & 0xffu) * (1.0f / 255.0f);
+  r.br = (float)(q >> 24) * (1.0f / 255.0f);
+  return r;
+}
+
+// i in [-1, w-1], j in [-1, h-1]
+__device__ __forceinline__ uint32_t quad_at(const KfDev& kf, const CamConsts& c, int i, int j) {
+  return gload(kf.quads + (size_t)(j + 1) * (size_t)(c.color_width + 1) + (size_t)(i + 1));
+}
+
+// Bilinear footprint of a sample at pixel-corner coordinates (x, y): base texel (clamped to the quad
+// table's range, which reproduces clamp addressing exactly) and the two filter weights.
+struct TexFootprint { int i, j; float a, b; };
+__device__ __forceinline__ TexFootprint tex_footprint(const CamConsts& c, float x, float y) {
   const float xb = x - 0.5f, yb = y - 0.5f;
   const float fx = floorf(xb), fy = floorf(yb);
-  float a = xb - fx, b = yb - fy;
-  if (mode == BSLAM_TEX_FIXED_POINT_1_8) {
-    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
-    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  TexFootprint f;
+  f.a = xb - fx;
+  f.b = yb - fy;
+  if (c.tex_mode == BSLAM_TEX_FIXED_POINT_1_8) {
+    f.a = floorf(f.a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    f.b = floorf(f.b * 256.0f + 0.5f) * (1.0f / 256.0f);
   }
-  const int i = (int)fminf(fmaxf(fx, -2.0f), (float)w);
-  const int j = (int)fminf(fmaxf(fy, -2.0f), (float)h);
-  const float t00 = texel_w(color, pitch, w, h, i, j);
-  const float t10 = texel_w(color, pitch, w, h, i + 1, j);
-  const float t01 = texel_w(color, pitch, w, h, i, j + 1);
-  const float t11 = texel_w(color, pitch, w, h, i + 1, j + 1);
+  f.i = (int)fminf(fmaxf(fx, -1.0f), (float)(c.color_width - 1));
+  f.j = (int)fminf(fmaxf(fy, -1.0f), (float)(c.color_height - 1));
+  return f;
+}
+__device__ __forceinline__ float tex_filter(const LumaQuad& t, float a, float b) {
   const float w00 = (1.0f - a) * (1.0f - b);
   const float w10 = a * (1.0f - b);
   const float w01 = (1.0f - a) * b;
   const float w11 = a * b;
-  return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+  return ((w00 * t.tl + w10 * t.tr) + w01 * t.bl) + w11 * t.br;
+}
+__device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, float x, float y) {
+  const TexFootprint f = tex_footprint(c, x, y);
+  return tex_filter(unpack_quad(quad_at(kf, c, f.i, f.j)), f.a, f.b);
 }
 
 // BS/cost_function.cuh:115-136
@@ -204,27 +238,32 @@ __device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_s
 
 // BS/cost_function.cuh:140-156
 __device__ __forceinline__ void raw_descriptor_residual(const KfDev& kf, const CamConsts& c, f2 pxy, f2 t1, f2 t2, float d1, float d2, float* r1, float* r2) {
-  const float intensity = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, pxy.x, pxy.y, c.tex_mode);
-  const float i1 = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, t1.x, t1.y, c.tex_mode);
-  const float i2 = tex_w(kf.color, kf.color_pitch, c.color_width, c.color_height, t2.x, t2.y, c.tex_mode);
+  const float intensity = tex_w(kf, c, pxy.x, pxy.y);
+  const float i1 = tex_w(kf, c, t1.x, t1.y);
+  const float i2 = tex_w(kf, c, t2.x, t2.y);
   *r1 = (180.f * (i1 - intensity)) - d1;
   *r2 = (180.f * (i2 - intensity)) - d2;
 }
 
-// one block of BS/cost_function.cuh:200-239
+// one block of BS/cost_function.cuh:200-239: base texel and weights of the gradient at p
+struct GradFootprint { int ix, iy; float tx, ty; };
+__device__ __forceinline__ GradFootprint grad_footprint(const CamConsts& c, f2 p) {
+  GradFootprint g;
+  g.ix = f2i(fmaxf(0.f, p.x - 0.5f));
+  g.iy = f2i(fmaxf(0.f, p.y - 0.5f));
+  g.tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - (float)g.ix));
+  g.ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - (float)g.iy));
+  g.ix = min(g.ix, c.color_width - 1);
+  g.iy = min(g.iy, c.color_height - 1);
+  return g;
+}
+__device__ __forceinline__ void grad_filter(const LumaQuad& t, const GradFootprint& g, float* dx, float* dy) {
+  *dx = (t.br - t.bl) * g.ty + (t.tr - t.tl) * (1 - g.ty);
+  *dy = (t.br - t.tr) * g.tx + (t.bl - t.tl) * (1 - g.tx);
+}
 __device__ __forceinline__ void point_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* dx, float* dy) {
-  int ix = f2i(fmaxf(0.f, p.x - 0.5f));
-  int iy = f2i(fmaxf(0.f, p.y - 0.5f));
-  const float tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - (float)ix));
-  const float ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - (float)iy));
-  ix = min(ix, c.color_width - 1);
-  iy = min(iy, c.color_height - 1);
-  const float tl = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix, iy);
-  const float tr = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix + 1, iy);
-  const float bl = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix, iy + 1);
-  const float br = texel_w(kf.color, kf.color_pitch, c.color_width, c.color_height, ix + 1, iy + 1);
-  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
-  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
+  const GradFootprint g = grad_footprint(c, p);
+  grad_filter(unpack_quad(quad_at(kf, c, g.ix, g.iy)), g, dx, dy);
 }
 
 // BS/cost_function.cuh:191-254 (without the three dead fetches :241-243)
@@ -234,6 +273,33 @@ __device__ __forceinline__ void descriptor_jacobian_wrt_projected_position(const
   point_gradient(kf, c, cp, &cdx, &cdy);
   point_gradient(kf, c, t1, &t1dx, &t1dy);
   point_gradient(kf, c, t2, &t2dx, &t2dy);
+  *gx1 = 180.f * (t1dx - cdx);
+  *gy1 = 180.f * (t1dy - cdy);
+  *gx2 = 180.f * (t2dx - cdx);
+  *gy2 = 180.f * (t2dy - cdy);
+}
+
+// Bilinear value and gradient at p from one gather: the sample's quad doubles as the gradient's
+// whenever both footprints start at the same texel (always, except in the half-pixel border strip).
+__device__ __forceinline__ void point_value_and_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* value, float* dx, float* dy) {
+  const TexFootprint f = tex_footprint(c, p.x, p.y);
+  const GradFootprint g = grad_footprint(c, p);
+  const uint32_t q = quad_at(kf, c, f.i, f.j);
+  uint32_t qg = q;
+  if (g.ix != f.i || g.iy != f.j) qg = quad_at(kf, c, g.ix, g.iy);
+  *value = tex_filter(unpack_quad(q), f.a, f.b);
+  grad_filter(unpack_quad(qg), g, dx, dy);
+}
+
+// raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers
+__device__ __forceinline__ void descriptor_residual_and_jacobian(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2, float d1, float d2,
+                                                                 float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
+  float intensity, i1, i2, cdx, cdy, t1dx, t1dy, t2dx, t2dy;
+  point_value_and_gradient(kf, c, cp, &intensity, &cdx, &cdy);
+  point_value_and_gradient(kf, c, t1, &i1, &t1dx, &t1dy);
+  point_value_and_gradient(kf, c, t2, &i2, &t2dx, &t2dy);
+  *r1 = (180.f * (i1 - intensity)) - d1;
+  *r2 = (180.f * (i2 - intensity)) - d2;
   *gx1 = 180.f * (t1dx - cdx);
   *gy1 = 180.f * (t1dy - cdy);
   *gx2 = 180.f * (t2dx - cdx);
@@ -280,6 +346,23 @@ __global__ __launch_bounds__(256) void build_records_kernel(CamConsts c, const K
   records[((size_t)k * c.height + y) * c.width + x] = make_uint2(__float_as_uint(depth), normal | (measured << 16));
 }
 
+// Luma quads of every keyframe's colour image (see KfDev::quads); grid (ceil((w+1)/256), h+1, K).
+__global__ __launch_bounds__(256) void build_quads_kernel(CamConsts c, const KfDev* __restrict__ kfs, uint32_t* __restrict__ quads) {
+  const int qx = blockIdx.x * blockDim.x + threadIdx.x;   // = i + 1
+  const int qy = blockIdx.y;                              // = j + 1
+  const int k = blockIdx.z;
+  const int w = c.color_width, h = c.color_height;
+  if (qx > w) return;
+  const KfDev& kf = kfs[k];
+  const int i0 = max(0, qx - 1), i1 = min(qx, w - 1);
+  const int j0 = max(0, qy - 1), j1 = min(qy, h - 1);
+  const uint8_t* r0 = kf.color + (size_t)j0 * kf.color_pitch;
+  const uint8_t* r1 = kf.color + (size_t)j1 * kf.color_pitch;
+  const uint32_t tl = r0[4 * (size_t)i0 + 3], tr = r0[4 * (size_t)i1 + 3];
+  const uint32_t bl = r1[4 * (size_t)i0 + 3], br = r1[4 * (size_t)i1 + 3];
+  quads[((size_t)k * (h + 1) + qy) * (size_t)(w + 1) + qx] = tl | (tr << 8) | (bl << 16) | (br << 24);
+}
+
 // gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
 // associated with the pixel it projects to.
 __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, Proj* r) {
@@ -295,7 +378,7 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   r->py = f2i(r->pxy.y);
   if (r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height) return false;
   // IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127
-  const uint2 rec = kf.records[(size_t)r->py * c.width + r->px];
+  const uint2 rec = gload_u2(kf.records + ((size_t)r->py * c.width + r->px));
   if (rec.y & ((uint32_t)BSLAM_INVALID_DEPTH_BIT << 16)) return false;
   r->depth = __uint_as_float(rec.x);
   r->raw_depth = rec.y >> 16;

@@ -228,10 +228,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
         f2 t1, t2;
         tangent_projections(gp, gn, r2, kf.frame_T_global, c, &t1, &t2);
-        float r1, rr2;
-        raw_descriptor_residual(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2);
-        float gx1, gy1, gx2, gy2;
-        descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+        float r1, rr2, gx1, gy1, gx2, gy2;
+        descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
         const float term1 = -c.cfx * (rn.x * p.local.z - rn.z * p.local.x);
         const float term2 = -c.cfy * (rn.y * p.local.z - rn.z * p.local.y);
         const float term3 = 1.f / (p.local.z * p.local.z);

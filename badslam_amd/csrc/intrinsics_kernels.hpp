@@ -98,12 +98,10 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
           f2 t1, t2;
           tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
-          float gx1, gy1, gx2, gy2;
-          descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+          float r1, rr2, gx1, gy1, gx2, gy2;
+          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           const float j1[4] = {gx1 * nx, gy1 * ny, gx1, gy1};
           const float j2[4] = {gx2 * nx, gy2 * ny, gx2, gy2};
-          float r1, rr2;
-          raw_descriptor_residual(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2);
           if (r1 != 0) {   // the reference uses "residual != 0" as the validity flag (:200, :208)
             const float w = desc_weight(r1);
             int idx = 20;

@@ -96,8 +96,7 @@ __device__ __forceinline__ DescTerms descriptor_terms(const CamConsts& c, const 
   DescTerms t;
   f2 t1, t2;
   tangent_projections(gp, gn, radius_squared, kf.frame_T_global, c, &t1, &t2);
-  raw_descriptor_residual(kf, c, color_pxy, t1, t2, d1, d2, &t.r1, &t.r2);
-  descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
+  descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1, d2, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
   t.gx1 *= c.cfx; t.gx2 *= c.cfx;
   t.gy1 *= c.cfy; t.gy2 *= c.cfy;
   t.w1 = desc_weight(t.r1);

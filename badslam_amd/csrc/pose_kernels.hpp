@@ -24,8 +24,16 @@
 namespace bslam {
 
 constexpr int kPoseThreads = 256;
-constexpr int kPoseR = 4;                      // surfels per thread
-constexpr int kPoseTile = kPoseThreads * kPoseR;
+// surfels per thread (granules per work slot): geometric-only and photometric variants are tuned
+// separately, the photometric one is register-heavy (tools/variants.py measures the choices)
+#ifndef BSLAM_POSE_R_GEO
+#define BSLAM_POSE_R_GEO 4
+#endif
+#ifndef BSLAM_POSE_R_DESC
+#define BSLAM_POSE_R_DESC 4
+#endif
+constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
+constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
 constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
 constexpr int kRowCost = 27;
 constexpr int kRowCount = 28;
@@ -63,7 +71,7 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
   for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fmaf(wr, J[i], acc[21 + i]);
 }
 
-template <bool kDepth, bool kDesc>
+template <bool kDepth, bool kDesc, int kPoseR>
 __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
     SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states) {
@@ -118,10 +126,8 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
         if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
           f2 t1, t2;
           tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
-          float r1, rr2;
-          raw_descriptor_residual(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2);
-          float gx1, gy1, gx2, gy2;
-          descriptor_jacobian_wrt_projected_position(kf, c, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
+          float r1, rr2, gx1, gy1, gx2, gy2;
+          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           gx1 *= c.cfx; gx2 *= c.cfx;
           gy1 *= c.cfy; gy2 *= c.cfy;
           descriptor_pose_jacobian(gx1, gy1, p.local, J);
