@@ -128,16 +128,43 @@ __device__ __forceinline__ f3 unpack_normal(uint32_t value) {
   return scale3(factor, n);
 }
 
+// Division / reciprocal / square root of the RESIDUAL math.  The reference builds its kernels with
+// -use_fast_math (BS/CMakeLists.txt:67), i.e. with approximate division and square root throughout; here
+//  - everything that feeds an INTEGER output (project_and_associate, normal quantisation) uses the correctly
+//    rounded forms, so associations / counts / packed normals are bit-identical to the oracle's;
+//  - level 1 (default): robust weights, inverse stddev and Jacobian factors use the 1-ulp v_rcp_f32
+//    (smooth functions: a 1-ulp input change is a ~1e-7 relative output change);
+//  - level 2 (opt-in): the tangent sample points too.  With the 1.8 fixed-point texture weights a 1-ulp
+//    move of a sample point can flip a quantised weight (a ~1e-4..1e-3 jump of one descriptor residual), which
+//    is why it is not the default;  level 0 = everything correctly rounded.
+#ifndef BSLAM_FAST_RESIDUAL_MATH
+#define BSLAM_FAST_RESIDUAL_MATH 1
+#endif
+#if BSLAM_FAST_RESIDUAL_MATH >= 1
+__device__ __forceinline__ float rdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rrcp(float b) { return __builtin_amdgcn_rcpf(b); }
+#else
+__device__ __forceinline__ float rdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float rrcp(float b) { return 1.f / b; }
+#endif
+#if BSLAM_FAST_RESIDUAL_MATH >= 2
+__device__ __forceinline__ float sdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+__device__ __forceinline__ float sdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float ssqrt(float x) { return sqrtf(x); }
+#endif
+
 // BS/robust_weighting.cuh:39-86
 __device__ __forceinline__ float tukey_weight(float r, float k) {
-  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return t * t; }
+  if (fabsf(r) < k) { const float q = rdiv(r, k); const float t = 1.f - q * q; return t * t; }
   return 0.f;
 }
 __device__ __forceinline__ float tukey_residual(float r, float k) {
-  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return (1 / 6.f) * k * k * (1 - t * t * t); }
+  if (fabsf(r) < k) { const float q = rdiv(r, k); const float t = 1.f - q * q; return (1 / 6.f) * k * k * (1 - t * t * t); }
   return (1 / 6.f) * k * k;
 }
-__device__ __forceinline__ float huber_weight(float r, float k) { const float a = fabsf(r); return (a < k) ? 1.f : (k / a); }
+__device__ __forceinline__ float huber_weight(float r, float k) { const float a = fabsf(r); return (a < k) ? 1.f : rdiv(k, a); }
 __device__ __forceinline__ float huber_residual(float r, float k) {
   const float a = fabsf(r);
   return (a < k) ? 0.5f * r * r : k * (a - 0.5f * k);
@@ -154,7 +181,7 @@ __device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, f
   return (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
 }
 __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
-  return baseline_fx / (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
+  return rdiv(baseline_fx, kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
 }
 __device__ __forceinline__ float depth_weight(float r) { return 1.f * tukey_weight(r, 1.f * kDepthTukey); }
 __device__ __forceinline__ float weighted_depth_residual(float r) { return 1.f * tukey_residual(r, 1.f * kDepthTukey); }
@@ -227,13 +254,16 @@ __device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, floa
 }
 
 // BS/cost_function.cuh:115-136
+__device__ __forceinline__ f2 project_sample(float fx, float fy, float cx, float cy, f3 p) {
+  return f2{fx * sdiv(p.x, p.z) + cx, fy * sdiv(p.y, p.z) + cy};
+}
 __device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_squared, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
   f3 t1 = cross(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
-  t1 = scale3(sqrtf(radius_squared / fmaxf(1e-12f, sqlen(t1))), scale3(2.0f, t1));
-  *t1_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t1)));
+  t1 = scale3(ssqrt(sdiv(radius_squared, fmaxf(1e-12f, sqlen(t1)))), scale3(2.0f, t1));
+  *t1_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t1)));
   f3 t2 = cross(gn, t1);
-  t2 = scale3(sqrtf(radius_squared / fmaxf(1e-12f, sqlen(t2))), scale3(2.0f, t2));
-  *t2_pxy = project(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t2)));
+  t2 = scale3(ssqrt(sdiv(radius_squared, fmaxf(1e-12f, sqlen(t2)))), scale3(2.0f, t2));
+  *t2_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t2)));
 }
 
 // BS/cost_function.cuh:140-156
@@ -411,7 +441,7 @@ __device__ __forceinline__ void depth_residual_and_jacobian(const CamConsts& c, 
 
 // Pose Jacobian of one descriptor residual (BS/kernel_opt_pose.cu:122-141).
 __device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 ls, float* J) {
-  const float inv_ls_z = 1.f / ls.z;
+  const float inv_ls_z = rrcp(ls.z);
   const float ls_z_sq = ls.z * ls.z;
   const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
   J[0] = -gx * inv_ls_z;

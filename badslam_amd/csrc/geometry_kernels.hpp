@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
         descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
         const float term1 = -c.cfx * (rn.x * p.local.z - rn.z * p.local.x);
         const float term2 = -c.cfy * (rn.y * p.local.z - rn.z * p.local.y);
-        const float term3 = 1.f / (p.local.z * p.local.z);
+        const float term3 = rrcp(p.local.z * p.local.z);
         const float jp1 = -(gx1 * term1 + gy1 * term2) * term3;
         const float jp2 = -(gx2 * term1 + gy2 * term2) * term3;
         const float jd = -1.f;

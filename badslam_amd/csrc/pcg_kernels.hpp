@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         if (P.optimize_geometry) {                               // :364-399
           const float term1 = -(rn.x * ls.z - rn.z * ls.x);
           const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-          const float term3 = 1.f / (ls.z * ls.z);
+          const float term3 = rrcp(ls.z * ls.z);
           const float jp1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
           const float jp2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
           ar[r][0] -= jp1 * t.w1 * t.r1 + jp2 * t.w2 * t.r2;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
         if (P.optimize_geometry) {
           const float term1 = -(rn.x * ls.z - rn.z * ls.x);
           const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-          const float term3 = 1.f / (ls.z * ls.z);
+          const float term3 = rrcp(ls.z * ls.z);
           gj1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
           gj2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
           sum_1 += gj1 * ps[r][0];

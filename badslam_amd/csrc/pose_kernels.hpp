@@ -30,7 +30,7 @@ constexpr int kPoseThreads = 256;
 #define BSLAM_POSE_R_GEO 4
 #endif
 #ifndef BSLAM_POSE_R_DESC
-#define BSLAM_POSE_R_DESC 4
+#define BSLAM_POSE_R_DESC 2
 #endif
 constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
 constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
