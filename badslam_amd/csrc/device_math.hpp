@@ -526,4 +526,27 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   return v[0] + __shfl_xor(v[0], 1, 64);
 }
 
+// Generic form for N = 8 or 16 values: N - 1 exchanges down to one value per lane, then log2(64 / N)
+// butterfly steps.  Afterwards every lane holds the wave total of column (lane / (64 / N)) % N.
+template <int N>
+__device__ __forceinline__ float wave_transpose_sum(float (&v)[N]) {
+  static_assert(N == 8 || N == 16, "N must be 8 or 16");
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t mask = 32;
+#pragma unroll
+  for (int n = N / 2; n >= 1; n >>= 1, mask >>= 1) {
+    const bool up = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float send = up ? v[i] : v[i + n];
+      const float keep = up ? v[i + n] : v[i];
+      v[i] = keep + __shfl_xor(send, mask, 64);
+    }
+  }
+  float total = v[0];
+#pragma unroll
+  for (uint32_t m = 32 / N; m >= 1; m >>= 1) total += __shfl_xor(total, m, 64);
+  return total;
+}
+
 }  // namespace bslam

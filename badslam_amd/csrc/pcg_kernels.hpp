@@ -23,7 +23,10 @@ constexpr float kAPriorWeight = 10.f;   // BS/kernel_pcg.cu:48
 constexpr uint32_t kInvalidUnknown = 0xffffffffu;
 
 constexpr int kPcgThreads = 256;
-constexpr int kPcgR = 2;
+#ifndef BSLAM_PCG_R
+#define BSLAM_PCG_R 2
+#endif
+constexpr int kPcgR = BSLAM_PCG_R;
 constexpr int kPcgTile = kPcgThreads * kPcgR;
 constexpr int kPcgPoseRow = 12;    // init: r[6], M[6];  step1: g[6] (+6 unused)
 constexpr int kPcgGlobRow = 20;    // init: depth intr r[5], M[5], colour r[4], M[4]; step1: alpha_d, g depth[5], g colour[4]
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       }
       __syncthreads();
       if (threadIdx.x < kPcgPoseRow)
-        partial_pose[((size_t)tile * kf_count + k) * kPcgPoseRow + threadIdx.x] =
+        partial_pose[((size_t)k * sc.slots + tile) * kPcgPoseRow + threadIdx.x] =
             ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x];
       parity ^= 1;
     }
@@ -268,32 +271,51 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   if (kIntr) block_reduce_rows<kPcgGlobRow>(glob, redg, partial_glob + (size_t)tile * kPcgGlobRow);
 }
 
-// Sums the per-tile pose rows of one keyframe and stores them at its unknown indices.
+// Sums the per-tile pose rows of one keyframe ([k][tile][12], contiguous per keyframe) and stores them at
+// its unknown indices.  The block walks the keyframe's rows as one flat array with a stride that is a
+// multiple of the row length, so a thread always sees the same column and loads are fully coalesced; the
+// 21 per-thread sums of a column are then added in a fixed order (deterministic).
 // mode 0: init (r, M get rows 0-5 / 6-11); mode 1: step1 (g gets rows 0-5).
-__global__ __launch_bounds__(64) void pcg_pose_reduce_kernel(const float* __restrict__ partial_pose, int tiles, int kf_count,
-                                                            const KfDev* __restrict__ kfs, PcgParams P, int mode) {
+constexpr int kPcgPoseReduceThreads = 21 * kPcgPoseRow;   // 252
+__global__ __launch_bounds__(kPcgPoseReduceThreads) void pcg_pose_reduce_kernel(const float* __restrict__ partial_pose, int tiles, int kf_count,
+                                                                               const KfDev* __restrict__ kfs, PcgParams P, int mode) {
   const int k = blockIdx.x;
   const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kfs[k].id);
   if (kf_idx == kInvalidUnknown) return;
-  const int col = threadIdx.x;
-  if (col >= kPcgPoseRow) return;
+  __shared__ float sm[21][kPcgPoseRow];
+  const int col = threadIdx.x % kPcgPoseRow, sub = threadIdx.x / kPcgPoseRow;
+  const float* base = partial_pose + (size_t)k * tiles * kPcgPoseRow;
+  const size_t n = (size_t)tiles * kPcgPoseRow;
   float v = 0.f;
-  for (int t = 0; t < tiles; ++t) v += partial_pose[((size_t)t * kf_count + k) * kPcgPoseRow + col];
+  for (size_t e = threadIdx.x; e < n; e += kPcgPoseReduceThreads) v += base[e];
+  sm[sub][col] = v;
+  __syncthreads();
+  if (threadIdx.x >= kPcgPoseRow) return;
+  float total = 0.f;
+  for (int i = 0; i < 21; ++i) total += sm[i][col];
   if (mode == 0) {
-    if (col < 6) P.r[kf_idx + col] = v; else P.M[kf_idx + col - 6] = v;
+    if (col < 6) P.r[kf_idx + col] = total; else P.M[kf_idx + col - 6] = total;
   } else {
-    if (col < 6) P.g[kf_idx + col] = v;
+    if (col < 6) P.g[kf_idx + col] = total;
   }
 }
 
 // Sums the per-tile global rows.  mode 0: init -> r, M of the intrinsics; mode 1: step1 -> alpha_d and g.
 // Adds to the destination (cfactor-independent entries were zeroed by the caller's memset).
-__global__ __launch_bounds__(64) void pcg_glob_reduce_kernel(const float* __restrict__ partial_glob, int tiles, PcgParams P, int mode,
-                                                            int kf_count, const float* __restrict__ eps_term) {
-  const int col = threadIdx.x;
-  if (col >= kPcgGlobRow) return;
+constexpr int kPcgGlobReduceThreads = 50 * kPcgGlobRow;   // 1000
+__global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(const float* __restrict__ partial_glob, int tiles, PcgParams P, int mode,
+                                                                               int kf_count, const float* __restrict__ eps_term) {
+  // same flat, coalesced walk as pcg_pose_reduce_kernel (one block: the rows are ~100 KB)
+  __shared__ float sm[50][kPcgGlobRow];
+  const int col = threadIdx.x % kPcgGlobRow, sub = threadIdx.x / kPcgGlobRow;
+  const size_t n = (size_t)tiles * kPcgGlobRow;
+  float part = 0.f;
+  for (size_t e = threadIdx.x; e < n; e += kPcgGlobReduceThreads) part += partial_glob[e];
+  sm[sub][col] = part;
+  __syncthreads();
+  if (threadIdx.x >= kPcgGlobRow) return;
   float v = 0.f;
-  for (int t = 0; t < tiles; ++t) v += partial_glob[(size_t)t * kPcgGlobRow + col];
+  for (int i = 0; i < 50; ++i) v += sm[i][col];
   if (mode == 0) {
     if (P.optimize_depth_intr) {
       if (col < 5) P.r[P.depth_intr_start + col] += v;
@@ -482,7 +504,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
       }
       __syncthreads();
       if (threadIdx.x < kPcgPoseRow)
-        partial_pose[((size_t)tile * kf_count + k) * kPcgPoseRow + threadIdx.x] = (threadIdx.x < 6)
+        partial_pose[((size_t)k * sc.slots + tile) * kPcgPoseRow + threadIdx.x] = (threadIdx.x < 6)
             ? ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x] : 0.f;
       parity ^= 1;
     }
