@@ -88,6 +88,7 @@ SIGNATURES = {
     "bslam_set_texture_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_set_xcd_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_set_keyframe_cache": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),

@@ -330,7 +330,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->order.release(); ctx->intr_cells.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->order.release(); ctx->intr_cells.release();
   ctx->staging.release(); ctx->staging2.release();
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
@@ -342,6 +342,13 @@ int bslam_set_texture_mode(bslam_context* ctx, int mode) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   if (mode != BSLAM_TEX_FIXED_POINT_1_8 && mode != BSLAM_TEX_EXACT_FLOAT) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown texture mode %d", mode);
   ctx->tex_mode = mode;
+  return BSLAM_OK;
+}
+
+int bslam_set_allreduce(bslam_context* ctx, bslam_allreduce_fn allreduce, void* allreduce_user) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->allreduce = allreduce;
+  ctx->allreduce_user = allreduce_user;
   return BSLAM_OK;
 }
 

@@ -84,6 +84,9 @@ struct bslam_context {
   bool keyframe_cache = false;
   std::vector<uint64_t> records_signature;
   // XCD-aware schedule (granule order), cached per surfel buffer
+  bslam::Slab exchange;      // staging of the multi-rank exchanges (PCG shared unknowns, intrinsics sums)
+  bslam_allreduce_fn allreduce = nullptr;   // bslam_set_allreduce: sum across the ranks of a surfel-sharded run
+  void* allreduce_user = nullptr;
   bslam::Slab order;
   bool use_schedule = true;
   const void* order_key_ptr = nullptr;

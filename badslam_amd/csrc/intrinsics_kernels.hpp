@@ -211,4 +211,12 @@ __global__ __launch_bounds__(256) void intrinsics_pixel_update_kernel(Intrinsics
   *cf = v;
 }
 
+// Observation counts <-> exactly representable floats, in place (multi-rank exchange of the cell sums).
+__global__ __launch_bounds__(256) void intrinsics_obs_convert_kernel(uint32_t* obs, int cells, int to_integer) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= cells) return;
+  if (to_integer) obs[p] = (uint32_t)__uint_as_float(obs[p]);
+  else obs[p] = __float_as_uint((float)obs[p]);
+}
+
 }  // namespace bslam

@@ -36,6 +36,9 @@ struct PcgParams {
   int gauge_kf;
   int optimize_poses, optimize_geometry, optimize_depth_intr, optimize_color_intr;
   int per_surfel;   // 1 (geometry only) or 3 (with descriptors)
+  // unknowns [shard_begin, shard_end) belong to this rank's surfel shard; all others (poses, intrinsics,
+  // cfactor cells) are shared between the ranks of a surfel-sharded run and are kept bit-identical on all
+  uint32_t shard_begin, shard_end;
   float* r; float* M; float* delta; float* g; float* p;
   float* alpha_n; float* alpha_d; float* beta_n;
 };
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kPcgPoseReduceThreads) void pcg_pose_reduce_kernel(
 // Adds to the destination (cfactor-independent entries were zeroed by the caller's memset).
 constexpr int kPcgGlobReduceThreads = 50 * kPcgGlobRow;   // 1000
 __global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(const float* __restrict__ partial_glob, int tiles, PcgParams P, int mode,
-                                                                               int kf_count, const float* __restrict__ eps_term) {
+                                                                               float* __restrict__ pairs_out) {
   // same flat, coalesced walk as pcg_pose_reduce_kernel (one block: the rows are ~100 KB)
   __shared__ float sm[50][kPcgGlobRow];
   const int col = threadIdx.x % kPcgGlobRow, sub = threadIdx.x / kPcgGlobRow;
@@ -327,11 +330,8 @@ __global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(
     }
   } else {
     if (col == 0) {
-      // alpha_d = sum over pairs + (epsilon term added once per keyframe: quirk Q7, BS/kernel_pcg.cu:1102-1113)
-      float a = v;
-      const float e = *eps_term;
-      for (int k = 0; k < kf_count; ++k) a += e;
-      *P.alpha_d = a;
+      // sum over this rank's pairs; pcg_alpha_d_kernel adds the epsilon terms (after the all-reduce, if any)
+      *pairs_out = v;
     } else if (col < 6) {
       if (P.optimize_depth_intr) P.g[P.depth_intr_start + col - 1] += v;
     } else if (col < 10) {
@@ -533,6 +533,32 @@ __device__ __forceinline__ float diag_extra(uint32_t i, uint32_t a_index) {
   return kDiagEpsilon + ((i == a_index) ? (kAPriorWeight * kAPriorWeight) : 0);
 }
 
+// Dot products are formed as (shared part) + (this rank's sharded part).  The vector kernels run on a
+// two-segment grid: blocks [0, sb) walk the SHARED unknowns in shared order (poses, then intrinsics / cfactor
+// cells), blocks [sb, sb + lb) walk this rank's sharded unknowns.  The shared part is therefore summed in an
+// order that does not depend on the shard size, so every rank of a surfel-sharded run forms bit-identical
+// shared sums; only the sharded part goes through the all-reduce.
+__host__ __device__ __forceinline__ uint32_t vec_shared_blocks(const PcgParams& P) {
+  return (P.unknown_count - (P.shard_end - P.shard_begin) + kVecTile - 1) / kVecTile;
+}
+__host__ __device__ __forceinline__ uint32_t vec_local_blocks(const PcgParams& P) {
+  return (P.shard_end - P.shard_begin + kVecTile - 1) / kVecTile;
+}
+// Unknown index of element j (0..kVecPerThread) of this thread, or false.
+__device__ __forceinline__ bool vec_element(const PcgParams& P, int j, uint32_t* i) {
+  const uint32_t shard_len = P.shard_end - P.shard_begin, shared = P.unknown_count - shard_len;
+  const uint32_t sb = vec_shared_blocks(P);
+  if (blockIdx.x < sb) {
+    const uint32_t u = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
+    if (u >= shared) return false;
+    *i = (u < P.shard_begin) ? u : u + shard_len;
+  } else {
+    const uint32_t u = (blockIdx.x - sb) * kVecTile + j * kVecThreads + threadIdx.x;
+    if (u >= shard_len) return false;
+    *i = P.shard_begin + u;
+  }
+  return true;
+}
 __device__ __forceinline__ void block_sum_to(float v, float* out) {
   __shared__ float sm[kVecThreads / 64];
   v = wave_sum(v);
@@ -546,8 +572,8 @@ __global__ __launch_bounds__(kVecThreads) void pcg_init2_kernel(PcgParams P, flo
   float acc = 0.f;
 #pragma unroll
   for (int j = 0; j < kVecPerThread; ++j) {
-    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
-    if (i < P.unknown_count) {
+    uint32_t i;
+    if (vec_element(P, j, &i)) {
       P.g[i] = 0;
       const float r_value = P.r[i] + ((i == P.a_index) ? (-kAPriorWeight * kAPriorWeight * a) : 0);
       const float p_value = r_value / (P.M[i] + kDiagEpsilon + ((i == P.a_index) ? (kAPriorWeight * kAPriorWeight) : 0));
@@ -564,8 +590,8 @@ __global__ __launch_bounds__(kVecThreads) void pcg_eps_kernel(PcgParams P, float
   float acc = 0.f;
 #pragma unroll
   for (int j = 0; j < kVecPerThread; ++j) {
-    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
-    if (i < P.unknown_count) { const float p = P.p[i]; acc += diag_extra(i, P.a_index) * p * p; }
+    uint32_t i;
+    if (vec_element(P, j, &i)) { const float p = P.p[i]; acc += diag_extra(i, P.a_index) * p * p; }
   }
   block_sum_to(acc, &partial[blockIdx.x]);
 }
@@ -577,8 +603,8 @@ __global__ __launch_bounds__(kVecThreads) void pcg_step2_kernel(PcgParams P, flo
   float acc = 0.f;
 #pragma unroll
   for (int j = 0; j < kVecPerThread; ++j) {
-    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
-    if (i < P.unknown_count) {
+    uint32_t i;
+    if (vec_element(P, j, &i)) {
       const float p_value = P.p[i];
       P.delta[i] += alpha * p_value;
       float r_value = P.r[i];
@@ -598,23 +624,60 @@ __global__ __launch_bounds__(kVecThreads) void pcg_step3_kernel(PcgParams P) {
   const float beta = (an >= 1e-35f) ? (*P.beta_n / an) : 0;
 #pragma unroll
   for (int j = 0; j < kVecPerThread; ++j) {
-    const uint32_t i = blockIdx.x * kVecTile + j * kVecThreads + threadIdx.x;
-    if (i < P.unknown_count) P.p[i] = P.g[i] + beta * P.p[i];
+    uint32_t i;
+    if (vec_element(P, j, &i)) P.p[i] = P.g[i] + beta * P.p[i];
   }
 }
 
-// Sums `n` block partials in index order into *out (one block).
-__global__ __launch_bounds__(256) void pcg_final_sum_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
-  __shared__ float sm[256];
-  float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
-  sm[threadIdx.x] = v;
+// Sums the block partials of the shared segment [0, sb) and of the sharded segment [sb, sb + lb) in a fixed
+// order, one block.  combine != 0: out[0] = shared + sharded.  combine == 0: out[0] = shared, out[1] = sharded
+// (the caller all-reduces out[1] across ranks and adds).
+__global__ __launch_bounds__(256) void pcg_final_sum_kernel(const float* __restrict__ partial, int sb, int lb, float* __restrict__ out, int combine) {
+  __shared__ float sm[2][256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < sb; i += 256) a += partial[i];
+  for (int i = threadIdx.x; i < lb; i += 256) b += partial[sb + i];
+  sm[0][threadIdx.x] = a;
+  sm[1][threadIdx.x] = b;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    if ((int)threadIdx.x < s) { sm[0][threadIdx.x] += sm[0][threadIdx.x + s]; sm[1][threadIdx.x] += sm[1][threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = sm[0];
+  if (threadIdx.x == 0) {
+    if (combine) out[0] = sm[0][0] + sm[1][0];
+    else { out[0] = sm[0][0]; out[1] = sm[1][0]; }
+  }
+}
+
+// Multi-rank exchange helpers: the shared unknowns of up to two vectors plus a few scalars travel in one
+// staging buffer [vec0 shared | vec1 shared | scalars].
+__global__ __launch_bounds__(256) void pcg_pack_shared_kernel(const float* __restrict__ v0, const float* __restrict__ v1, uint32_t n,
+                                                              uint32_t shard_begin, uint32_t shard_end, float* __restrict__ stage) {
+  const uint32_t shared = n - (shard_end - shard_begin);
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= shared) return;
+  const uint32_t i = (j < shard_begin) ? j : j + (shard_end - shard_begin);
+  stage[j] = v0[i];
+  if (v1) stage[shared + j] = v1[i];
+}
+__global__ __launch_bounds__(256) void pcg_unpack_shared_kernel(float* __restrict__ v0, float* __restrict__ v1, uint32_t n,
+                                                                uint32_t shard_begin, uint32_t shard_end, const float* __restrict__ stage) {
+  const uint32_t shared = n - (shard_end - shard_begin);
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= shared) return;
+  const uint32_t i = (j < shard_begin) ? j : j + (shard_end - shard_begin);
+  v0[i] = stage[j];
+  if (v1) v1[i] = stage[shared + j];
+}
+// out = s[0] + s[1]
+__global__ void pcg_add2_kernel(const float* __restrict__ s, float* __restrict__ out) { *out = s[0] + s[1]; }
+// alpha_d = pairs + kf_count x (eps_shared + eps_sharded)   (quirk Q7: the epsilon term is added once per keyframe)
+__global__ void pcg_alpha_d_kernel(const float* __restrict__ pairs, const float* __restrict__ eps2, int kf_count, float* __restrict__ alpha_d) {
+  float a = *pairs;
+  const float e = eps2[0] + eps2[1];
+  for (int k = 0; k < kf_count; ++k) a += e;
+  *alpha_d = a;
 }
 
 // UpdateSurfelsFromPCGDeltaCUDAKernel BS/kernel_pcg.cu:1305-1333

@@ -201,6 +201,12 @@ DirectBA::~DirectBA() {
   if (ctx_) bslam_destroy(ctx_);
 }
 
+void DirectBA::SetAllReduce(bslam_allreduce_fn fn, void* user) {
+  allreduce_ = fn;
+  allreduce_user_ = user;
+  Check(bslam_set_allreduce(ctx_, fn, user), "bslam_set_allreduce");
+}
+
 void DirectBA::InvalidateKeyframeCache() { Check(bslam_invalidate_keyframe_cache(ctx_), "bslam_invalidate_keyframe_cache"); }
 
 void DirectBA::SetTextureMode(int mode) { Check(bslam_set_texture_mode(ctx_, mode), "bslam_set_texture_mode"); }

@@ -187,7 +187,9 @@ class DirectBA {
   // cfactor image in place (the class does it itself for the changes it makes).
   void InvalidateKeyframeCache();
   void SetTimingsStream(std::ostream* s) { timings_stream_ = s; }   // --save_timings format of BS/direct_ba_alternating.cc:630-688
-  void SetAllReduce(bslam_allreduce_fn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
+  // Surfel-sharded multi-GPU runs: `fn` sums device buffers across ranks (RCCL / torch.distributed); it is
+  // used by the batched pose step and, through the context, by the PCG and intrinsics entry points.
+  void SetAllReduce(bslam_allreduce_fn fn, void* user);
 
   void Lock() const { ba_thread_mutex_.lock(); }
   void Unlock() const { ba_thread_mutex_.unlock(); }

@@ -331,6 +331,19 @@ int bslam_debug_pose_residuals(
     const bslam_depth_params* depth_params, const bslam_keyframe_view* keyframe,
     uint32_t surfels_size, const bslam_buffer2d* surfels, float* out);
 
+/* Multi-GPU (surfel-sharded) runs of the PCG and intrinsics entry points: every rank holds its own
+ * surfel shard and the full keyframe list; `allreduce` sums a device buffer of floats in place across
+ * ranks (ordered after prior work on `stream`, e.g. RCCL ncclAllReduce on that stream).  It is
+ * called at fixed points with sizes that are identical on all ranks:
+ *   bslam_pcg_init   1 x  [r | M] of the shared unknowns (poses, intrinsics, cfactor cells)
+ *   bslam_pcg_init2  1 x  1 float (sharded part of alpha_n)
+ *   bslam_pcg_step1  1 x  [g of the shared unknowns | 2 floats]
+ *   bslam_pcg_step2  1 x  1 float (sharded part of beta_n)
+ *   bslam_optimize_intrinsics  1 x  40 floats (A, b1, colour H, b), and with depth intrinsics 1 x  8 floats per cfactor cell
+ * All ranks then hold bit-identical shared unknowns without any broadcast.  NULL (default) = single GPU.
+ * The reference is single-GPU; this replaces nothing in it. */
+int bslam_set_allreduce(bslam_context* ctx, bslam_allreduce_fn allreduce, void* allreduce_user);
+
 /* ------------------------------------------------------------------------- */
 /* PCG (matrix-free Gauss-Newton step)                                        */
 /* ------------------------------------------------------------------------- */

@@ -80,3 +80,93 @@ def test_two_ranks_sharded_pose_estimation_matches_single_process(tmp_path, orac
     # and the optimisation did something: it moved the 4 mm / 1 mrad perturbed estimates back to the truth
     truth = _pose_array([kf.global_T_frame for kf in scene.keyframes])
     assert np.abs(single - truth).max() < 1e-4 < np.abs(_pose_array(init) - truth).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# PCG and intrinsics under sharding, through the C++ host class
+# ------------------------------------------------------------------------------------------------
+def _ba_scene():
+    from tests import bso, scenes
+    scene = scenes.synthetic_scene(4, seed=21, use_depth_residuals=True, use_descriptor_residuals=False)
+    rng = np.random.default_rng(4)
+    n = scene.surfels_size
+    scene.surfels[2, :n] += rng.uniform(-0.003, 0.003, n).astype(np.float32)
+    for kf in scene.keyframes[1:]:
+        x = np.concatenate([rng.uniform(-0.002, 0.002, 3), rng.uniform(-0.0005, 0.0005, 3)]).astype(np.float32)
+        kf.global_T_frame = bso.se3_mul(kf.global_T_frame, bso.se3_exp(x))
+    return scene
+
+
+def _run_ba(scene, lo, hi, use_pcg, depth_intr, hook=None):
+    from badslam_amd.direct_ba import DirectBA
+    ba = DirectBA(max(1, hi - lo), scene.raw_to_float_depth, scene.baseline_fx, scene.cell, 0.8, 1, 1, 1,
+                  scene.color_camera, scene.depth_camera, 0, scene.use_depth_residuals, scene.use_descriptor_residuals)
+    ba.set_options(pcg_gauge_keyframe=0, texture_mode=scene.tex_mode)
+    if hook is not None:
+        ba.set_allreduce(hook.callback)
+    for kf in scene.keyframes:
+        ba.AddKeyframe(kf.id, max(kf.min_depth, 1e-3), max(kf.max_depth, 1e-2), kf.depth, kf.normals, kf.radius, kf.color, kf.global_T_frame)
+    ba.SetSurfels(np.ascontiguousarray(scene.surfels[:8, lo:hi]), hi - lo)
+    if depth_intr:
+        d = scene.depth_camera
+        ba.set_intrinsics(None, [d.fx + 0.3, d.fy - 0.4, d.cx + 0.5, d.cy - 0.6], 0.0)
+    for i in range(3):
+        ba.BundleAdjustment(depth_intr, False, False, True, True, 2, 2, use_pcg, 0, len(scene.keyframes) - 1, True)
+    poses = _pose_array([ba.keyframe_pose(k) for k in range(len(scene.keyframes))])
+    _, dc, a = ba.intrinsics()
+    return poses, ba.GetSurfels(8), np.concatenate([dc, [a]]).astype(np.float32)
+
+
+def _ba_worker(rank, world, port, out_dir, use_pcg, depth_intr):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from badslam_amd.distributed import AllReduceHook, shard_range
+    from tests import bso
+    bso.build_oracle()
+    scene = _ba_scene()
+    lo, hi = shard_range(scene.surfels_size, rank, world)
+    hook = AllReduceHook(device=True)
+    poses, surfels, intr = _run_ba(scene, lo, hi, use_pcg, depth_intr, hook)
+    assert hook.calls > 0
+    np.save(os.path.join(out_dir, f"ba_poses_{rank}.npy"), poses)
+    np.save(os.path.join(out_dir, f"ba_surfels_{rank}.npy"), surfels)
+    np.save(os.path.join(out_dir, f"ba_intr_{rank}.npy"), intr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_pcg,depth_intr", [(True, False), (True, True), (False, True)])
+def test_two_ranks_sharded_bundle_adjustment(tmp_path, oracle, use_pcg, depth_intr):
+    """Three BA calls (poses + geometry [+ depth intrinsics]) with the surfels split over two ranks equal the
+    single-process run: shared unknowns (poses, intrinsics) are bit-identical on both ranks and agree with
+    the single-process values, and every rank's surfels agree with the matching slice."""
+    import torch.multiprocessing as mp
+    from badslam_amd.distributed import shard_range
+    world = 2
+    mp.spawn(_ba_worker, args=(world, _free_port(), str(tmp_path), use_pcg, depth_intr), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "ba_poses_0.npy"), np.load(tmp_path / "ba_poses_1.npy")
+    i0, i1 = np.load(tmp_path / "ba_intr_0.npy"), np.load(tmp_path / "ba_intr_1.npy")
+    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+    assert np.array_equal(i0.view(np.uint32), i1.view(np.uint32))
+    scene = _ba_scene()
+    before = _pose_array([kf.global_T_frame for kf in scene.keyframes])
+    poses, surfels, intr = _run_ba(scene, 0, scene.surfels_size, use_pcg, depth_intr)
+    moved = np.abs(poses - before).max()
+    assert moved > 1e-4
+    # different fp32 summation orders, amplified by the truncated conjugate-gradient solve: 1 % of the update
+    # (5 % when the weakly constrained depth-deformation unknowns are part of the same PCG system)
+    bar = (5e-2 if (use_pcg and depth_intr) else 1e-2) * moved
+    assert np.abs(p0 - poses).max() < bar, (np.abs(p0 - poses).max(), moved)
+    assert np.allclose(i0[:4], intr[:4], rtol=1e-4), (i0, intr)
+    assert abs(i0[4] - intr[4]) < 1e-3, (i0, intr)   # `a` is weakly constrained (the reference's own bar on it is 1e-2)
+    for rank in range(world):
+        lo, hi = shard_range(scene.surfels_size, rank, world)
+        got = np.load(tmp_path / f"ba_surfels_{rank}.npy")
+        dz = np.abs(got[:3] - surfels[:3, lo:hi]).max(axis=0)
+        # surfel updates are ~3 mm here; a few surfels sit at an association threshold and flip with the
+        # (slightly different) poses, everything else agrees to a fraction of a percent of the update
+        assert np.quantile(dz, 0.999) < (1e-4 if (use_pcg and depth_intr) else 2e-5) and dz.max() < 5e-4, (rank, float(np.quantile(dz, 0.999)), float(dz.max()))
