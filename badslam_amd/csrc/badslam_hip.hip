@@ -118,8 +118,6 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   const size_t bytes = table.size() * sizeof(KfDev);
   int rc = ctx->kf_table.reserve(bytes);
   if (rc) return rc;
-  rc = ctx->staging.reserve(bytes);
-  if (rc) return rc;
   const size_t rec_per_kf = (size_t)c.width * c.height;
   if ((rc = ctx->records.reserve(table.size() * rec_per_kf * sizeof(uint2)))) return rc;
   for (size_t k = 0; k < table.size(); ++k) table[k].records = (const uint2*)ctx->records.ptr + k * rec_per_kf;
@@ -131,33 +129,38 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   } else {
     for (size_t k = 0; k < table.size(); ++k) table[k].quads = nullptr;
   }
-  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
-  std::memcpy(ctx->staging.ptr, table.data(), bytes);
-  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, ctx->staging.ptr, bytes, hipMemcpyHostToDevice, stream));
-  // derived pixel records: rebuilt on every call because the caller owns (and may have rewritten) the
-  // depth / normal / cfactor images between calls -- unless the caller promised otherwise
-  // (bslam_set_keyframe_cache) and nothing the records depend on has changed since they were built
-  bool rebuild = true;
+  void* stage = nullptr;
+  if ((rc = ctx->upload_ring.acquire(bytes, &stage))) return rc;
+  std::memcpy(stage, table.data(), bytes);
+  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->kf_table.ptr, stage, bytes, hipMemcpyHostToDevice, stream));
+  if ((rc = ctx->upload_ring.commit(stream))) return rc;
+  // derived pixel records / luma quads: rebuilt on every call because the caller owns (and may have rewritten)
+  // the depth / normal / colour / cfactor images between calls -- unless the caller promised otherwise
+  // (bslam_set_keyframe_cache) and nothing they depend on has changed since they were built
+  bool rebuild_records = true, rebuild_quads = with_color;
   if (ctx->keyframe_cache) {
     std::vector<uint64_t> sig;
-    sig.reserve(table.size() * 4 + 8);
-    for (const KfDev& kf : table) {
-      sig.push_back((uint64_t)kf.depth); sig.push_back((uint64_t)kf.normals); sig.push_back(((uint64_t)kf.depth_pitch << 32) | kf.normals_pitch);
-      sig.push_back((uint64_t)kf.color); sig.push_back((uint64_t)kf.color_pitch);
-    }
-    sig.push_back(with_color ? (uint64_t)ctx->quads.ptr : 0); sig.push_back(((uint64_t)c.color_width << 32) | (uint32_t)c.color_height);
+    sig.reserve(table.size() * 3 + 8);
+    for (const KfDev& kf : table) { sig.push_back((uint64_t)kf.depth); sig.push_back((uint64_t)kf.normals); sig.push_back(((uint64_t)kf.depth_pitch << 32) | kf.normals_pitch); }
     uint32_t fa, fr; std::memcpy(&fa, &c.a, 4); std::memcpy(&fr, &c.raw_to_float_depth, 4);
     sig.push_back((uint64_t)c.cfactor); sig.push_back(((uint64_t)c.cfactor_pitch << 32) | (uint32_t)c.cell);
     sig.push_back(((uint64_t)fa << 32) | fr); sig.push_back(((uint64_t)c.width << 32) | (uint32_t)c.height);
     sig.push_back((uint64_t)ctx->records.ptr);
-    if (sig == ctx->records_signature) rebuild = false; else ctx->records_signature.swap(sig);
+    if (sig == ctx->records_signature) rebuild_records = false; else ctx->records_signature.swap(sig);
+    if (with_color) {
+      std::vector<uint64_t> qs;
+      qs.reserve(table.size() * 2 + 2);
+      for (const KfDev& kf : table) { qs.push_back((uint64_t)kf.color); qs.push_back((uint64_t)kf.color_pitch); }
+      qs.push_back((uint64_t)ctx->quads.ptr); qs.push_back(((uint64_t)c.color_width << 32) | (uint32_t)c.color_height);
+      if (qs == ctx->quads_signature) rebuild_quads = false; else ctx->quads_signature.swap(qs);
+    }
   }
-  if (rebuild && !table.empty() && table[0].depth != nullptr) {
+  if (rebuild_records && !table.empty() && table[0].depth != nullptr) {
     hipLaunchKernelGGL(build_records_kernel, dim3((unsigned)((c.width + 255) / 256), (unsigned)c.height, (unsigned)table.size()), dim3(256), 0, stream,
                        c, (const KfDev*)ctx->kf_table.ptr, (uint2*)ctx->records.ptr);
     BSLAM_HIP_TRY(hipGetLastError());
   }
-  if (rebuild && with_color) {
+  if (rebuild_quads) {
     hipLaunchKernelGGL(build_quads_kernel, dim3((unsigned)((c.color_width + 1 + 255) / 256), (unsigned)(c.color_height + 1), (unsigned)table.size()), dim3(256), 0, stream,
                        c, (const KfDev*)ctx->kf_table.ptr, (uint32_t*)ctx->quads.ptr);
     BSLAM_HIP_TRY(hipGetLastError());
@@ -263,7 +266,7 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
 
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
-                                  int* tiles_out) {
+                                  int* tiles_out, bool final_sum = true) {
   Schedule sc;
   const int R = use_desc ? kPoseRDesc : kPoseRGeo;
   int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &sc);
@@ -294,9 +297,16 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   // at most rows * 256 -- exact in fp32 up to 2^24, i.e. up to 65k rows per part (134M surfels per keyframe)
   hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count, kReduceParts), dim3(256), 0, stream, (const float*)partials, rows_per_kf, kf_count, parts, states);
   BSLAM_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
-  BSLAM_HIP_TRY(hipGetLastError());
+  if (final_sum) {   // otherwise the caller's pose_final_solve_kernel adds the parts itself
+    hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
+    BSLAM_HIP_TRY(hipGetLastError());
+  }
   return BSLAM_OK;
+}
+
+// Device address of the stage-A parts [K][kReduceParts][kRow] written by launch_pose_accumulate.
+static const float* pose_parts_ptr(const bslam_context* ctx, int tiles, int kf_count) {
+  return (const float*)ctx->partials.ptr + (size_t)tiles * (kPoseThreads / 64) * kf_count * kRow;
 }
 
 }  // namespace bslam
@@ -331,7 +341,8 @@ int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
   ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->order.release(); ctx->intr_cells.release();
-  ctx->staging.release(); ctx->staging2.release();
+  ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
+  for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
   delete ctx;
@@ -356,12 +367,14 @@ int bslam_set_keyframe_cache(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->keyframe_cache = enable != 0;
   ctx->records_signature.clear();
+  ctx->quads_signature.clear();
   return BSLAM_OK;
 }
 
 int bslam_invalidate_keyframe_cache(bslam_context* ctx) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->records_signature.clear();
+  ctx->quads_signature.clear();
   return BSLAM_OK;
 }
 
@@ -529,38 +542,68 @@ int bslam_estimate_frame_poses_batched(
   const size_t state_bytes = states.size() * sizeof(PoseState);
   if ((rc = ctx->pose_state.reserve(state_bytes))) return rc;
   if ((rc = ctx->staging2.reserve(state_bytes + 64))) return rc;
-  std::memcpy(ctx->staging2.ptr, states.data(), state_bytes);
-  BSLAM_HIP_TRY(hipMemcpyAsync(ctx->pose_state.ptr, ctx->staging2.ptr, state_bytes, hipMemcpyHostToDevice, stream));
-  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  {
+    void* stage = nullptr;
+    if ((rc = ctx->upload_ring.acquire(state_bytes, &stage))) return rc;
+    std::memcpy(stage, states.data(), state_bytes);
+    BSLAM_HIP_TRY(hipMemcpyAsync(ctx->pose_state.ptr, stage, state_bytes, hipMemcpyHostToDevice, stream));
+    if ((rc = ctx->upload_ring.commit(stream))) return rc;
+  }
 
   PoseState* d_states = (PoseState*)ctx->pose_state.ptr;
-  int* d_active = (int*)ctx->misc.ptr;
-  int* h_active = (int*)((uint8_t*)ctx->staging2.ptr + state_bytes);
+  int* d_active = (int*)ctx->misc.ptr;                                     // [4]: one counter per in-flight iteration
+  int* h_active = (int*)((uint8_t*)ctx->staging2.ptr + state_bytes);       // [4]
+  for (hipEvent_t& e : ctx->iter_done)
+    if (!e) BSLAM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   hipLaunchKernelGGL(pose_init_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream, keyframe_count,
                      (const PoseState*)d_states, (KfDev*)ctx->kf_table.ptr);
   BSLAM_HIP_TRY(hipGetLastError());
 
-  for (int it = 0; it < max_iterations; ++it) {
-    BSLAM_HIP_TRY(hipMemsetAsync(d_active, 0, sizeof(int), stream));
-    if (surfels_size > 0) {
+  // One Gauss-Newton iteration of all unconverged keyframes, ending with the number of keyframes still
+  // unconverged on its way to h_active[it % 4].
+  auto enqueue_iteration = [&](int it) -> int {
+    const int slot = it & 3;
+    BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
+    if (surfels_size > 0 && !allreduce) {
       int tiles = 0;
-      if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles))) return rc;
+      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false);
+      if (r) return r;
+      hipLaunchKernelGGL(pose_final_solve_kernel, dim3((unsigned)keyframe_count), dim3(64), 0, stream, pose_parts_ptr(ctx, tiles, keyframe_count),
+                         keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
+      BSLAM_HIP_TRY(hipGetLastError());
     } else {
-      if ((rc = ctx->coeffs.reserve((size_t)keyframe_count * kRow * sizeof(float)))) return rc;
-      BSLAM_HIP_TRY(hipMemsetAsync(ctx->coeffs.ptr, 0, (size_t)keyframe_count * kRow * sizeof(float), stream));   // H.setZero(); b.setZero() (:147-149)
+      if (surfels_size > 0) {
+        int tiles = 0;
+        int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles);
+        if (r) return r;
+      } else {
+        int r = ctx->coeffs.reserve((size_t)keyframe_count * kRow * sizeof(float));
+        if (r) return r;
+        BSLAM_HIP_TRY(hipMemsetAsync(ctx->coeffs.ptr, 0, (size_t)keyframe_count * kRow * sizeof(float), stream));   // H.setZero(); b.setZero() (:147-149)
+      }
+      if (allreduce) {
+        // converged keyframes keep stale rows; they are identical on every rank because every rank
+        // applied identical updates, and the solve kernel ignores them.
+        const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
+        if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
+      }
+      hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
+                         (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
+      BSLAM_HIP_TRY(hipGetLastError());
     }
-    if (allreduce) {
-      // converged keyframes keep stale rows; they are identical on every rank because every rank
-      // applied identical updates, and the solve kernel ignores them.
-      const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
-      if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
-    }
-    hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
-                       (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active);
-    BSLAM_HIP_TRY(hipGetLastError());
-    BSLAM_HIP_TRY(hipMemcpyAsync(h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
-    BSLAM_HIP_TRY(hipStreamSynchronize(stream));
-    if (*h_active == 0) break;
+    BSLAM_HIP_TRY(hipMemcpyAsync(h_active + slot, d_active + slot, sizeof(int), hipMemcpyDeviceToHost, stream));
+    BSLAM_HIP_TRY(hipEventRecord(ctx->iter_done[slot], stream));
+    return BSLAM_OK;
+  };
+  // The host learns "all converged" one iteration late: iteration it + 1 is already enqueued while the flag of
+  // iteration it travels back, so the GPU never idles on the round trip.  An iteration enqueued after
+  // convergence is a no-op on the device (every kernel skips converged keyframes), so poses, iteration counts
+  // and flags are the same as with a blocking check after every iteration.
+  if (max_iterations > 0 && (rc = enqueue_iteration(0))) return rc;
+  for (int it = 0; it < max_iterations; ++it) {
+    if (it + 1 < max_iterations && (rc = enqueue_iteration(it + 1))) return rc;
+    BSLAM_HIP_TRY(hipEventSynchronize(ctx->iter_done[it & 3]));
+    if (h_active[it & 3] == 0) break;
   }
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, d_states, state_bytes, hipMemcpyDeviceToHost, stream));
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));

@@ -64,6 +64,48 @@ struct PinnedSlab {
   void release() { if (ptr) { hipError_t e = hipHostFree(ptr); (void)e; } ptr = nullptr; bytes = 0; }
 };
 
+// Ring of pinned upload buffers: an API call takes the next slot for its small host->device uploads and
+// records an event after enqueuing the copy, so calls do not have to drain the stream before re-using
+// staging memory (the wait only happens if the ring wraps onto a copy that has not finished yet).
+struct StagingRing {
+  static constexpr int kSlots = 8;
+  PinnedSlab slot[kSlots];
+  hipEvent_t done[kSlots] = {};
+  bool pending[kSlots] = {};
+  int next = 0;
+  int cur = 0;
+  int acquire(size_t bytes, void** out) {
+    cur = next;
+    next = (next + 1) % kSlots;
+    if (pending[cur]) {
+      hipError_t e = hipEventSynchronize(done[cur]);
+      if (e != hipSuccess) return fail(BSLAM_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+      pending[cur] = false;
+    }
+    int rc = slot[cur].reserve(bytes);
+    if (rc) return rc;
+    *out = slot[cur].ptr;
+    return BSLAM_OK;
+  }
+  int commit(hipStream_t stream) {   // after the copies out of the acquired slot were enqueued
+    if (!done[cur]) {
+      hipError_t e = hipEventCreateWithFlags(&done[cur], hipEventDisableTiming);
+      if (e != hipSuccess) return fail(BSLAM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipEventRecord(done[cur], stream);
+    if (e != hipSuccess) return fail(BSLAM_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    pending[cur] = true;
+    return BSLAM_OK;
+  }
+  void release() {
+    for (int i = 0; i < kSlots; ++i) {
+      if (done[i]) { hipError_t e = hipEventDestroy(done[i]); (void)e; done[i] = nullptr; }
+      slot[i].release();
+      pending[i] = false;
+    }
+  }
+};
+
 }  // namespace bslam
 
 struct bslam_context {
@@ -80,9 +122,12 @@ struct bslam_context {
   bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
+  bslam::StagingRing upload_ring;   // keyframe table / pose state uploads
+  hipEvent_t iter_done[4] = {};     // batched pose loop: one event per in-flight iteration
   // derived-record cache (bslam_set_keyframe_cache)
   bool keyframe_cache = false;
-  std::vector<uint64_t> records_signature;
+  std::vector<uint64_t> records_signature;   // what the depth records were built from
+  std::vector<uint64_t> quads_signature;     // what the luma quads were built from
   // XCD-aware schedule (granule order), cached per surfel buffer
   bslam::Slab exchange;      // staging of the multi-rank exchanges (PCG shared unknowns, intrinsics sums)
   bslam_allreduce_fn allreduce = nullptr;   // bslam_set_allreduce: sum across the ranks of a surfel-sharded run

@@ -370,4 +370,43 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
   if (!st.converged) atomicAdd(active_count, 1);
 }
 
+// pose_reduce_final_kernel + pose_solve_kernel in one launch (single-GPU path: no exchange between the
+// two): block k adds the stage-A parts of keyframe k into LDS, thread 0 solves and updates the pose.
+__global__ __launch_bounds__(64) void pose_final_solve_kernel(const float* __restrict__ parts, int kf_count, PoseState* __restrict__ states,
+                                                             KfDev* __restrict__ kfs, int* __restrict__ active_count) {
+  const int k = blockIdx.x;
+  if (states[k].converged) return;   // uniform
+  __shared__ float row[kRow];
+  const int col = threadIdx.x;
+  if (col < 27) {
+    float total = 0.f;
+    for (int p = 0; p < kReduceParts; ++p) total += parts[((size_t)k * kReduceParts + p) * kRow + col];
+    row[col] = total;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  PoseState st = states[k];
+  float H[21], b[6], x[6];
+  for (int i = 0; i < 21; ++i) H[i] = row[i];
+  for (int i = 0; i < 6; ++i) b[i] = row[21 + i];
+  solve_ldlt6(H, b, x);
+  float neg[6];
+  for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
+  Quat dq; f3 dt;
+  se3_exp(neg, &dq, &dt);
+  Quat q{st.q[0], st.q[1], st.q[2], st.q[3]};
+  f3 t = mk3(st.t[0], st.t[1], st.t[2]);
+  se3_mul_inplace(&q, &t, dq, dt);
+  const float sc = 1e-06f / 1e-07f;   // IsScale1PoseEstimationConverged BS/convergence_analysis.h:45-52
+  float nrm = 0.f;
+  for (int i = 0; i < 6; ++i) { const float v = (i < 3) ? x[i] : x[i] * sc; nrm += v * v; }
+  st.q[0] = q.x; st.q[1] = q.y; st.q[2] = q.z; st.q[3] = q.w;
+  st.t[0] = t.x; st.t[1] = t.y; st.t[2] = t.z;
+  st.iterations += 1;
+  st.converged = (nrm < 1e-06f) ? 1 : 0;
+  states[k] = st;
+  se3_inverse_matrix(q, t, kfs[k].frame_T_global.m);
+  if (!st.converged) atomicAdd(active_count, 1);
+}
+
 }  // namespace bslam

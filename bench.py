@@ -36,8 +36,8 @@ B_POSITION = {False: 25, True: 49}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--keyframes", type=int, default=50)
     ap.add_argument("--photometric", type=int, default=0, help="1: photometric+geometric residuals (config 3 shape)")
     ap.add_argument("--cpu-baseline", type=int, default=1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects PMC counters for bench.py in separate passes (never combined with tracing).
-# usage: tools_pmc.sh <outdir-under-gpurun_out> [bench args...]
+# usage: tools/pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
