@@ -257,7 +257,10 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
 
 // Chooses how many keyframes one block walks: enough blocks to fill 256 CUs several times over.
 static int choose_kfs_per_block(int tiles, int kf_count) {
-  const int target_blocks = 8192;
+#ifndef BSLAM_POSE_TARGET_BLOCKS
+#define BSLAM_POSE_TARGET_BLOCKS 8192
+#endif
+  const int target_blocks = BSLAM_POSE_TARGET_BLOCKS;
   int chunks = (target_blocks + tiles - 1) / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > kf_count) chunks = kf_count;

@@ -160,7 +160,7 @@ def main():
                    "in_bounds_pair_fraction": frac_inb, "associated_pair_fraction": assoc.value / pairs_per_pass,
                    "parallelism": f"surfel-shard x{world}"},
         "roofline": {"bound": "hbm", "kernel": "pose_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(use_desc, "pose_accumulate_kernel"),
                      "avg_launch_us": avg_launch_s * 1e6, "launches": launches.value,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "geometry_kernel": geometry_roofline(S, K, frac_inb, assoc.value / pairs_per_pass, use_desc, glaunches.value, gms.value)},
@@ -174,6 +174,17 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(use_desc, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written
+    from tools/pmc.sh runs of this same command; counters cannot be read from inside the timed process), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["photo" if use_desc else "geo"].get(kernel)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def geometry_roofline(S, K, frac_inb, frac_assoc, use_desc, launches, total_ms):
     """Second kernel of the BA iteration: normals pass + position (or position+descriptor) pass per launch."""
     if launches == 0 or total_ms <= 0:
@@ -182,13 +193,15 @@ def geometry_roofline(S, K, frac_inb, frac_assoc, use_desc, launches, total_ms):
     nbytes = pairs * (frac_inb * B_NORMALS + (1 - frac_inb) * B_REJECTED) + pairs * (frac_inb * B_POSITION[use_desc] + (1 - frac_inb) * B_REJECTED)
     avg_s = total_ms / 1e3 / launches
     ach = nbytes / avg_s / 1e9
-    return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": nbytes}
+    return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": nbytes,
+            "traffic": pmc_traffic(use_desc, "geometry_kernel")}
 
 
 def cpu_baseline(stack, K, use_desc, budget_s):
     """The oracle (kind "port": this repo's CPU restatement; the reference has no CPU cost
     evaluation) timed on the host cores on a bounded sample: whole pose passes
-    (all surfels x all keyframes) of the same stack, repeated until ~budget_s have elapsed."""
+    (all surfels x all keyframes, OpenMP tasks over keyframe x surfel chunk on every host thread) of the same
+    stack, repeated until ~budget_s have elapsed."""
     from badslam_amd import abi
     from tests import bso
     L = bso.lib()
@@ -218,7 +231,7 @@ def cpu_baseline(stack, K, use_desc, budget_s):
     pairs = passes * stack.surfels_size * K
     return {"value": pairs / el, "unit": "pairs/s", "cores": int(used), "kind": "port",
             "sample": f"{passes} pose-coefficient passes over {stack.surfels_size} surfels x {K} keyframes "
-                      f"({el:.1f} s, OpenMP over keyframes)"}
+                      f"({el:.1f} s, OpenMP over keyframe x surfel-chunk tasks)"}
 
 
 if __name__ == "__main__":
