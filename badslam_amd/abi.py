@@ -89,6 +89,14 @@ SIGNATURES = {
     "bslam_set_xcd_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_set_keyframe_cache": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "bslam_determine_supporting_surfels_and_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, P(Camera4f), P(DepthParams), P(KeyframeView),
+                                                              C.c_uint32, P(Buffer2D), P(C.c_uint32)]),
+    "bslam_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), P(DepthParams),
+                                                   P(KeyframeView), P(Mat3x4), C.c_int, P(KeyframeView), P(Mat3x4), C.c_uint32, P(Buffer2D),
+                                                   P(C.c_uint32)]),
+    "bslam_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(Camera4f), P(DepthParams), C.c_int, P(KeyframeView),
+                                                       P(C.c_uint32), C.c_uint32, P(Buffer2D)]),
+    "bslam_compact_surfels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32), P(Buffer2D), P(Buffer2D)]),
     "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),

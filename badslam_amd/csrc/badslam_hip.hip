@@ -11,6 +11,7 @@
 #include "geometry_kernels.hpp"
 #include "intrinsics_kernels.hpp"
 #include "pcg_kernels.hpp"
+#include "lifecycle_kernels.hpp"
 #include "pose_kernels.hpp"
 
 namespace bslam {
@@ -53,11 +54,13 @@ static CamConsts make_cam_consts(const bslam_context* ctx, const bslam_camera4f*
 }
 
 static void fill_kf(KfDev* d, const bslam_buffer2d* depth, const bslam_buffer2d* normals, const bslam_buffer2d* color,
-                    const bslam_mat3x4* frame_T_global, const bslam_mat3x3* global_R_frame, int activation, int id) {
+                    const bslam_mat3x4* frame_T_global, const bslam_mat3x3* global_R_frame, int activation, int id,
+                    const bslam_buffer2d* radius = nullptr) {
   std::memset(d, 0, sizeof(*d));
   d->depth = (const uint8_t*)depth->address;     d->depth_pitch = (uint32_t)depth->pitch;
   d->normals = (const uint8_t*)normals->address; d->normals_pitch = (uint32_t)normals->pitch;
   if (color) { d->color = (const uint8_t*)color->address; d->color_pitch = (uint32_t)color->pitch; }
+  if (radius) { d->radius = (const uint8_t*)radius->address; d->radius_pitch = (uint32_t)radius->pitch; }
   std::memcpy(d->frame_T_global.m, frame_T_global->m, sizeof(float) * 12);
   if (global_R_frame) std::memcpy(d->global_R_frame, global_R_frame->m, sizeof(float) * 9);
   d->activation = activation;
@@ -169,7 +172,7 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
 }
 
 static int build_kf_table(const bslam_camera4f* depth_camera, const bslam_camera4f* color_camera, bool need_color,
-                          int keyframe_count, const bslam_keyframe_view* keyframes, std::vector<KfDev>* table) {
+                          int keyframe_count, const bslam_keyframe_view* keyframes, std::vector<KfDev>* table, bool need_radius = false) {
   table->resize((size_t)keyframe_count);
   for (int k = 0; k < keyframe_count; ++k) {
     const bslam_keyframe_view& v = keyframes[k];
@@ -181,7 +184,12 @@ static int build_kf_table(const bslam_camera4f* depth_camera, const bslam_camera
       rc = check_image(&v.color, color_camera, 4, "keyframe color");
       if (rc) return rc;
     }
-    fill_kf(&(*table)[k], &v.depth, &v.normals, need_color ? &v.color : nullptr, &v.frame_T_global, &v.global_R_frame, v.activation, v.id);
+    if (need_radius) {
+      rc = check_image(&v.radius, depth_camera, 2, "keyframe radius");
+      if (rc) return rc;
+    }
+    fill_kf(&(*table)[k], &v.depth, &v.normals, need_color ? &v.color : nullptr, &v.frame_T_global, &v.global_R_frame, v.activation, v.id,
+            need_radius ? &v.radius : nullptr);
   }
   return BSLAM_OK;
 }
@@ -343,7 +351,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->order.release(); ctx->intr_cells.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->order.release(); ctx->intr_cells.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
@@ -748,3 +756,4 @@ int bslam_debug_pose_residuals(
 
 #include "intrinsics_abi.inc"
 #include "pcg_abi.inc"
+#include "lifecycle_abi.inc"

@@ -71,6 +71,7 @@ struct KfDev {
   const uint8_t* depth;    uint32_t depth_pitch;
   const uint8_t* normals;  uint32_t normals_pitch;
   const uint8_t* color;    uint32_t color_pitch;
+  const uint8_t* radius;   uint32_t radius_pitch;   // half radius^2 image (only the surfel lifecycle reads it)
   // derived per-pixel records {f32 calibrated depth, u16 pixel normal, u16 raw depth}, row pitch in
   // records = image width (library-owned, rebuilt by build_records_kernel)
   const uint2* records;

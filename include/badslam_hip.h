@@ -331,6 +331,50 @@ int bslam_debug_pose_residuals(
     const bslam_depth_params* depth_params, const bslam_keyframe_view* keyframe,
     uint32_t surfels_size, const bslam_buffer2d* surfels, float* out);
 
+/* ------------------------------------------------------------------------- */
+/* Surfel lifecycle                                          */
+/* ------------------------------------------------------------------------- */
+/* The reference resolves cell ownership with atomicCAS races; these entry points fix the outcome to
+ * "lowest surfel index first" / "raster order first" (one of the outcomes the reference can produce), so
+ * results are deterministic.  The supporting-surfel cell buffers (BS/direct_ba.cc:135) are library scratch. */
+
+/* Replaces DetermineSupportingSurfelsAndMergeSurfelsCUDA (BS/kernels.h:105-117): merged surfels get
+ * x = NaN (0x7fffffff); *surfel_count is decreased by their number (valid on return). */
+int bslam_determine_supporting_surfels_and_merge(
+    bslam_context* ctx, void* stream, float merge_dist_factor,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    const bslam_keyframe_view* keyframe, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    uint32_t* surfel_count);
+
+/* Replaces DetermineSupportingSurfelsCUDA + CreateSurfelsForKeyframeCUDA, i.e. the body of
+ * DirectBA::CreateSurfelsForKeyframe (BS/direct_ba.cc:340-405, BS/kernels.h:94-145).
+ * global_T_frame: the keyframe's pose as 3x4; covis_T_frame[i] = covis frame_T_global * global_T_frame
+ * (computed by the caller, BS/direct_ba.cc:365-370; only read when filter_new_surfels).
+ * Appends at column surfels_size; *new_surfel_count is valid on return.  If the new surfels do not fit,
+ * nothing is created and BSLAM_ERR_OUT_OF_MEMORY is returned (the reference logs an error). */
+int bslam_create_surfels_for_keyframe(
+    bslam_context* ctx, void* stream, int filter_new_surfels, int min_observation_count,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params,
+    const bslam_keyframe_view* keyframe, const bslam_mat3x4* global_T_frame,
+    int covis_count, const bslam_keyframe_view* covis_keyframes, const bslam_mat3x4* covis_T_frame,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, uint32_t* new_surfel_count);
+
+/* Replaces DeleteSurfelsAndUpdateRadiiCUDA (BS/kernels.h:271-280): surfels observed by fewer than
+ * min_observation_count keyframes, or with more free-space violations than observations, get x = NaN;
+ * the others get radius^2 = min over their observations. */
+int bslam_delete_surfels_and_update_radii(
+    bslam_context* ctx, void* stream, int min_observation_count,
+    const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t* surfel_count, uint32_t surfels_size, const bslam_buffer2d* surfels);
+
+/* Replaces CompactSurfelsCUDA (BS/kernels.h:292-299): the last valid surfels move into the free spots, in the
+ * reference's order; rows 0-7 (and active_surfels, may be NULL) move, *surfels_size becomes surfel_count. */
+int bslam_compact_surfels(
+    bslam_context* ctx, void* stream, uint32_t surfel_count, uint32_t* surfels_size,
+    const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels);
+
 /* Multi-GPU (surfel-sharded) runs of the PCG and intrinsics entry points: every rank holds its own
  * surfel shard and the full keyframe list; `allreduce` sums a device buffer of floats in place across
  * ranks (ordered after prior work on `stream`, e.g. RCCL ncclAllReduce on that stream).  It is

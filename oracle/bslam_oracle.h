@@ -152,15 +152,49 @@ void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_
                           const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,
                           float* min_depth, float* max_depth);
 
-/* DirectBA::CreateSurfelsForKeyframe with filter_new_surfels = false
- * (BS/direct_ba.cc:340-405; BS/kernel_supporting_surfels.cu:45-97 without merge;
- * BS/kernel_create_surfels.cu:41-161,357-385).  Cell ownership is decided in raster /
- * surfel-index order (the reference's atomicCAS race is not reproducible).  Appends at
- * *surfels_size and returns the number of surfels created. */
+float bso_half_to_float(uint16_t h);   /* IEEE binary16 -> float (__half2float) */
+
+/* ---- surfel lifecycle ------------------------------------------------------
+ * The reference decides cell ownership with atomicCAS races (BS/kernel_supporting_surfels.cu:58,
+ * BS/kernel_create_surfels.cu:62); any interleaving is a valid outcome.  The oracle (and the HIP
+ * kernels) use the interleaving "lowest surfel index / raster order first". */
+
+/* DetermineSupportingSurfelsCUDA / DetermineSupportingSurfelsAndMergeSurfelsCUDA
+ * (BS/kernel_supporting_surfels.{cu,cc}).  supporting[3] are cell images (cells_h x cells_w u32, row-major,
+ * kInvalidIndex = 0xffffffff).  With merge != 0 merged surfels get x = NaN (0x7fffffff) and *surfel_count
+ * is decreased. */
+void bso_determine_supporting_surfels(
+    int merge, float merge_dist_factor, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    const bslam_keyframe_view* kf, uint32_t surfels_size, const bslam_buffer2d* surfels,
+    uint32_t* supporting0, uint32_t* supporting1, uint32_t* supporting2, uint32_t* surfel_count);
+
+/* DirectBA::CreateSurfelsForKeyframe (BS/direct_ba.cc:340-405, BS/kernel_create_surfels.{cu,cc}).
+ * global_T_frame: the keyframe's pose matrix; covis_*: the co-visible keyframes and
+ * covis_frame_T_global * global_T_frame per entry (only used when filter_new_surfels).
+ * Appends at *surfels_size and returns the number of surfels created; creates none if they would not fit
+ * (the reference logs an error and returns, BS/kernel_create_surfels.cc:162-165). */
+uint32_t bso_create_surfels_for_keyframe_ex(
+    int filter_new_surfels, int min_observation_count,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp, const bslam_keyframe_view* kf, const bslam_mat3x4* global_T_frame,
+    int covis_count, const bslam_keyframe_view* covis_keyframes, const bslam_mat3x4* covis_T_frame,
+    uint32_t* surfels_size, uint32_t max_surfels, const bslam_buffer2d* surfels, int tex_mode);
+
+/* filter_new_surfels = false, pose given as SE3 (scene builder of the known-answer tests) */
 uint32_t bso_create_surfels_for_keyframe(
     const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
     const bslam_depth_params* dp, const bslam_keyframe_view* kf, const bslam_se3f* global_T_frame,
     uint32_t* surfels_size, uint32_t max_surfels, const bslam_buffer2d* surfels, int tex_mode);
+
+/* DeleteSurfelsAndUpdateRadiiCUDA (BS/kernel_delete_surfels.{cu,cc}) */
+void bso_delete_surfels_and_update_radii(
+    int min_observation_count, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t* surfel_count, uint32_t surfels_size,
+    const bslam_buffer2d* surfels);
+
+/* CompactSurfelsCUDA (BS/kernel_compact_surfels.cu:111-281); active_surfels may be NULL */
+void bso_compact_surfels(uint32_t surfel_count, uint32_t* surfels_size, const bslam_buffer2d* surfels,
+                         const bslam_buffer2d* active_surfels);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ static uint16_t float_to_half_rn(float f) {
   return (uint16_t)(sign | half);
 }
 
-static float half_to_float(uint16_t h) {
+float bso_half_to_float(uint16_t h) {
   uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
   uint32_t exp = (h >> 10) & 0x1f;
   uint32_t mant = h & 0x3ffu;
@@ -179,71 +179,4 @@ void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_
   free(tmp);
   if (min_depth_out) *min_depth_out = min_depth;
   if (max_depth_out) *max_depth_out = max_depth;
-}
-
-uint32_t bso_create_surfels_for_keyframe(
-    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
-    const bslam_depth_params* dp, const bslam_keyframe_view* kf, const bslam_se3f* global_T_frame,
-    uint32_t* surfels_size, uint32_t max_surfels, const bslam_buffer2d* surfels, int tex_mode) {
-  const int w = kf->depth.width, h = kf->depth.height;
-  const int cell = dp->sparse_surfel_cell_size;
-  const int cw = (w - 1) / cell + 1, ch = (h - 1) / cell + 1;
-  bso_unprojector unproj = bso_make_unprojector(depth_camera);
-  bso_depth_to_color d2c = bso_make_depth_to_color(depth_camera, color_camera);
-  bslam_mat3x4 global_T_frame_m;
-  bso_se3_matrix3x4(global_T_frame, &global_T_frame_m);
-
-  /* DetermineSupportingSurfelsCUDAKernel<.., false> BS/kernel_supporting_surfels.cu:45-97:
-   * only "cell occupied or not" matters for creation. */
-  uint8_t* occupied = (uint8_t*)calloc((size_t)cw * ch, 1);
-  for (uint32_t i = 0; i < *surfels_size; ++i) {
-    bso_projection r;
-    if (bso_surfel_projects_to_associated_pixel(i, *surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r))
-      occupied[(size_t)(r.py / cell) * cw + (r.px / cell)] = 1;
-  }
-  /* CreateSurfelsForKeyframeCUDASerializingKernel BS/kernel_create_surfels.cu:41-72 (raster order wins the cell),
-   * inclusive scan (:427-460), CreationAppendKernel (:357-385) + CreateNewSurfel (:96-161). */
-  uint32_t created = 0;
-  for (int y = 0; y < h; ++y) {
-    for (int x = 0; x < w; ++x) {
-      const int kBorder = 1;
-      if (!(x >= kBorder && y >= kBorder && x < w - kBorder && y < h - kBorder)) continue;
-      uint16_t d16 = BSO_AT(uint16_t, &kf->depth, y, x);
-      if (d16 & BSLAM_INVALID_DEPTH_BIT) continue;
-      uint8_t* occ = &occupied[(size_t)(y / cell) * cw + (x / cell)];
-      if (*occ) continue;
-      *occ = 1;
-      if (*surfels_size + created >= max_surfels) continue;   /* BS/kernel_create_surfels.cc:162-165 logs and skips */
-      uint32_t si = *surfels_size + created;
-      ++created;
-      float calibrated_depth = bso_raw_to_calibrated_depth(dp->a, BSO_AT(float, &dp->cfactor_buffer, y / cell, x / cell), dp->raw_to_float_depth, d16);
-      bso_f3 gp = bso_mul34(&global_T_frame_m, bso_unproject(&unproj, x, y, calibrated_depth));
-      bso_surfel_set_position(surfels, si, gp);
-      bso_f3 ln = bso_u16_to_image_space_normal(BSO_AT(uint16_t, &kf->normals, y, x));
-      bso_f3 gn = bso_rotate34(&global_T_frame_m, ln);
-      bso_surfel_set_normal(surfels, si, gn);
-      float radius_squared = half_to_float(BSO_AT(uint16_t, &kf->radius, y, x));
-      BSO_AT(float, surfels, BSLAM_SURFEL_RADIUS_SQUARED, si) = radius_squared;
-      bso_f2 pc = {x + 0.5f, y + 0.5f};
-      bso_f2 color_pxy;
-      bso_depth_to_color_pxy(pc, &d2c, &color_pxy);
-      /* colour: tex2D<float4> at color_pxy, stored as u8 (rgb); the path never reads it back,
-       * nearest texel is used here (the reference interpolates). */
-      int cxi = (int)fminf(fmaxf(color_pxy.x, 0.f), (float)(kf->color.width - 1));
-      int cyi = (int)fminf(fmaxf(color_pxy.y, 0.f), (float)(kf->color.height - 1));
-      const uint8_t* cp = (const uint8_t*)kf->color.address + (size_t)cyi * kf->color.pitch + 4 * (size_t)cxi;
-      uint8_t col[4] = {cp[0], cp[1], cp[2], 0};
-      memcpy(&BSO_AT(float, surfels, BSLAM_SURFEL_COLOR, si), col, 4);
-      bso_f2 t1, t2;
-      /* note: the UNQUANTISED global normal gn is used here, as in the reference (:124-131) */
-      bso_tangent_projections(gp, gn, radius_squared, &kf->frame_T_global, color_camera->fx, color_camera->fy, color_camera->cx, color_camera->cy, &t1, &t2);
-      float d1, d2;
-      bso_raw_descriptor_residual(&kf->color, tex_mode, color_pxy, t1, t2, 0, 0, &d1, &d2);
-      BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR1, si) = d1;
-      BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR2, si) = d2;
-    }
-  }
-  free(occupied);
-  *surfels_size += created;
-  return created;
 }

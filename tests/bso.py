@@ -71,6 +71,11 @@ def lib():
         "bso_compute_brightness": (None, [C.c_int, C.c_int, C.c_void_p, _BUF]),
         "bso_preprocess_depth": (None, [_CAM, _DP, _BUF, _BUF, _BUF, _BUF, f32p, f32p]),
         "bso_create_surfels_for_keyframe": (C.c_uint32, [_CAM, _CAM, _DP, _KFS, P(abi.SE3f), u32p, C.c_uint32, _BUF, C.c_int]),
+        "bso_create_surfels_for_keyframe_ex": (C.c_uint32, [C.c_int, C.c_int, _CAM, _CAM, _DP, _KFS, P(abi.Mat3x4), C.c_int, _KFS, P(abi.Mat3x4),
+                                                            u32p, C.c_uint32, _BUF, C.c_int]),
+        "bso_determine_supporting_surfels": (None, [C.c_int, C.c_float, _CAM, _DP, _KFS, C.c_uint32, _BUF, u32p, u32p, u32p, u32p]),
+        "bso_delete_surfels_and_update_radii": (None, [C.c_int, _CAM, _DP, C.c_int, _KFS, u32p, C.c_uint32, _BUF]),
+        "bso_compact_surfels": (None, [C.c_uint32, u32p, _BUF, _BUF]),
         "bso_bench_pose_pass": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, C.c_int, f32p, u32p, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -249,6 +254,54 @@ class HostScene:
         self.active[0, self.surfels_size:size.value] = abi.BSLAM_SURFEL_ACTIVE_FLAG
         self.surfels_size = size.value
         return n
+
+    # --- surfel lifecycle (oracle)
+    def covis_args(self, kf, covis):
+        """(count, KeyframeView[count], Mat3x4[count]) with covis_T_frame = covis frame_T_global * kf global_T_frame
+        (BS/direct_ba.cc:365-370)."""
+        n = len(covis)
+        views = (abi.KeyframeView * max(1, n))()
+        mats = (abi.Mat3x4 * max(1, n))()
+        for i, ck in enumerate(covis):
+            views[i] = ck.view()
+            mats[i] = se3_matrix3x4(se3_mul(se3_inverse(ck.global_T_frame), kf.global_T_frame))
+        return n, views, mats
+
+    def create_surfels_for_keyframe_ex(self, kf, filter_new_surfels, min_observation_count, covis):
+        """DirectBA::CreateSurfelsForKeyframe (BS/direct_ba.cc:340-405) with the observation-count filter."""
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        n, views, mats = self.covis_args(kf, covis)
+        G = se3_matrix3x4(kf.global_T_frame)
+        size = C.c_uint32(self.surfels_size)
+        created = lib().bso_create_surfels_for_keyframe_ex(int(filter_new_surfels), min_observation_count, C.byref(self.color_camera),
+                                                           C.byref(self.depth_camera), C.byref(dp), C.byref(v), C.byref(G), n, views, mats,
+                                                           C.byref(size), self.max_surfels, C.byref(sb), self.tex_mode)
+        self.active[0, self.surfels_size:size.value] = abi.BSLAM_SURFEL_ACTIVE_FLAG
+        self.surfels_size = size.value
+        return created
+
+    def merge_surfels(self, kf, merge_dist_factor, surfel_count):
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        cells = self.cfactor.shape[0] * self.cfactor.shape[1]
+        sup = [np.zeros(cells, np.uint32) for _ in range(3)]
+        cnt = C.c_uint32(surfel_count)
+        lib().bso_determine_supporting_surfels(1, merge_dist_factor, C.byref(self.depth_camera), C.byref(dp), C.byref(v), self.surfels_size, C.byref(sb),
+                                               sup[0].ctypes.data_as(P(C.c_uint32)), sup[1].ctypes.data_as(P(C.c_uint32)),
+                                               sup[2].ctypes.data_as(P(C.c_uint32)), C.byref(cnt))
+        return cnt.value
+
+    def delete_surfels_and_update_radii(self, min_observation_count, surfel_count):
+        dp, sb, kfs = self.depth_params(), self.surfel_buf(), self.keyframe_views()
+        cnt = C.c_uint32(surfel_count)
+        lib().bso_delete_surfels_and_update_radii(min_observation_count, C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs,
+                                                  C.byref(cnt), self.surfels_size, C.byref(sb))
+        return cnt.value
+
+    def compact_surfels(self, surfel_count, with_active=True):
+        sb, ab = self.surfel_buf(), self.active_buf()
+        size = C.c_uint32(self.surfels_size)
+        lib().bso_compact_surfels(surfel_count, C.byref(size), C.byref(sb), C.byref(ab) if with_active else None)
+        self.surfels_size = size.value
 
     # --- oracle calls on the host state
     def association(self, kf):

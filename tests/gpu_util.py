@@ -133,6 +133,52 @@ class Hip:
         self.torch.cuda.synchronize()
 
 
+    # --- surfel lifecycle
+    def create_surfels_for_keyframe(self, kf_index, filter_new_surfels, min_observation_count, covis_indices):
+        dp, sb = self._common()
+        kf = self.h.keyframes[kf_index]
+        v = self.d.keyframe_view(kf_index)
+        n = len(covis_indices)
+        views = (abi.KeyframeView * max(1, n))()
+        for i, ci in enumerate(covis_indices):
+            views[i] = self.d.keyframe_view(ci)
+        from tests import bso
+        _, _, mats = self.h.covis_args(kf, [self.h.keyframes[ci] for ci in covis_indices])
+        G = bso.se3_matrix3x4(kf.global_T_frame)
+        created = C.c_uint32()
+        badslam_amd.check(self.L.bslam_create_surfels_for_keyframe(
+            self.ctx.handle, stream_ptr(), int(filter_new_surfels), min_observation_count, C.byref(self.h.color_camera), C.byref(self.h.depth_camera),
+            C.byref(dp), C.byref(v), C.byref(G), n, views, mats, self.d.surfels_size, C.byref(sb), C.byref(created)))
+        self.d.surfels_size += created.value
+        return created.value
+
+    def merge_surfels(self, kf_index, merge_dist_factor, surfel_count):
+        dp, sb = self._common()
+        v = self.d.keyframe_view(kf_index)
+        cnt = C.c_uint32(surfel_count)
+        badslam_amd.check(self.L.bslam_determine_supporting_surfels_and_merge(
+            self.ctx.handle, stream_ptr(), merge_dist_factor, C.byref(self.h.depth_camera), C.byref(dp), C.byref(v), self.d.surfels_size, C.byref(sb),
+            C.byref(cnt)))
+        return cnt.value
+
+    def delete_surfels_and_update_radii(self, min_observation_count, surfel_count):
+        dp, sb = self._common()
+        kfs = self.d.keyframe_views()
+        cnt = C.c_uint32(surfel_count)
+        badslam_amd.check(self.L.bslam_delete_surfels_and_update_radii(
+            self.ctx.handle, stream_ptr(), min_observation_count, C.byref(self.h.depth_camera), C.byref(dp), len(self.h.keyframes), kfs,
+            C.byref(cnt), self.d.surfels_size, C.byref(sb)))
+        return cnt.value
+
+    def compact_surfels(self, surfel_count, with_active=True):
+        sb, ab = self.d.surfel_buf(), self.d.active_buf()
+        size = C.c_uint32(self.d.surfels_size)
+        badslam_amd.check(self.L.bslam_compact_surfels(self.ctx.handle, stream_ptr(), surfel_count, C.byref(size), C.byref(sb),
+                                                       C.byref(ab) if with_active else None))
+        self.torch.cuda.synchronize()
+        self.d.surfels_size = size.value
+
+
 class HipPCG:
     """PCG vectors in HBM + the HIP PCG entry points."""
     NAMES = ("r", "M", "delta", "g", "p")
