@@ -46,6 +46,8 @@ def host_lib():
     L.bsh_upload_keyframe_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
     L.bsh_upload_keyframe_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
     L.bsh_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.bsh_set_scheme_end_tasks.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_create_surfels_for_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.bsh_set_allreduce.argtypes = [C.c_void_p, abi.ALLREDUCE_FN, C.c_void_p]
     L.bsh_estimate_frame_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p]
     L.bsh_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -159,8 +161,12 @@ class DirectBA:
         d = np.ascontiguousarray(normals, np.uint16)
         self._check(self.L.bsh_upload_keyframe_normals(self._ba, self.stream, kf_id, d.ctypes.data_as(C.POINTER(C.c_uint16))))
 
-    def set_options(self, batched_pose_optimization=True, pcg_gauge_keyframe=-1, texture_mode=abi.TEX_FIXED_POINT_1_8):
+    def set_options(self, batched_pose_optimization=True, pcg_gauge_keyframe=-1, texture_mode=abi.TEX_FIXED_POINT_1_8, scheme_end_tasks=True):
         self._check(self.L.bsh_set_options(self._ba, int(batched_pose_optimization), pcg_gauge_keyframe, texture_mode))
+        self._check(self.L.bsh_set_scheme_end_tasks(self._ba, int(scheme_end_tasks)))
+
+    def CreateSurfelsForKeyframe(self, filter_new_surfels, kf_id):
+        self._check(self.L.bsh_create_surfels_for_keyframe(self._ba, self.stream, int(filter_new_surfels), kf_id))
 
     def set_allreduce(self, callback):
         self._check(self.L.bsh_set_allreduce(self._ba, callback, None))

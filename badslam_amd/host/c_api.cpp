@@ -99,6 +99,14 @@ int bsh_upload_keyframe_normals(void* ba, void* stream, int id, const uint16_t* 
   });
 }
 
+int bsh_set_scheme_end_tasks(void* ba, int enable) { BSH_TRY(static_cast<DirectBA*>(ba)->SetSchemeEndTasks(enable != 0)); }
+int bsh_create_surfels_for_keyframe(void* ba, void* stream, int filter_new_surfels, int keyframe_id) {
+  BSH_TRY({
+    DirectBA* b = static_cast<DirectBA*>(ba);
+    b->CreateSurfelsForKeyframe(static_cast<hipStream_t>(stream), filter_new_surfels != 0, b->keyframes().at(keyframe_id));
+  });
+}
+
 int bsh_set_options(void* ba, int batched_pose_optimization, int pcg_gauge_keyframe, int texture_mode) {
   BSH_TRY({
     DirectBA* b = static_cast<DirectBA*>(ba);

@@ -261,6 +261,84 @@ std::vector<bslam_keyframe_view> DirectBA::KeyframeViews() const {
   return v;
 }
 
+// BS/direct_ba.cc:340-405
+void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const std::shared_ptr<Keyframe>& keyframe) {
+  const bslam_camera4f color_cam = color_camera_.pod(), depth_cam = depth_camera_.pod();
+  const bslam_depth_params dp = depth_params();
+  const bslam_buffer2d surfels = surfels_->ToPod();
+  const bslam_keyframe_view view = keyframe->view();
+  const bslam_mat3x4 global_T_frame = keyframe->global_T_frame().Matrix3x4();
+  std::vector<bslam_keyframe_view> covis;
+  std::vector<bslam_mat3x4> covis_T_frame;
+  for (int index : keyframe->co_visibility_list()) {   // :365-370
+    const auto& other = keyframes_[index];
+    if (!other) continue;
+    covis.push_back(other->view());
+    covis_T_frame.push_back((other->frame_T_global() * keyframe->global_T_frame()).Matrix3x4());
+  }
+  u32 new_surfel_count = 0;
+  Check(bslam_create_surfels_for_keyframe(ctx_, stream, filter_new_surfels, GetMinObservationCount(), &color_cam, &depth_cam, &dp, &view,
+                                          &global_T_frame, static_cast<int>(covis.size()), covis.data(), covis_T_frame.data(), surfels_size_,
+                                          &surfels, &new_surfel_count),
+        "bslam_create_surfels_for_keyframe");
+  Lock();
+  surfels_size_ += new_surfel_count;
+  surfel_count_ += new_surfel_count;
+  Unlock();
+}
+
+void DirectBA::MergeAndCompact(hipStream_t stream, const std::vector<u32>& keyframe_ids) {
+  const bslam_camera4f depth_cam = depth_camera_.pod();
+  const bslam_depth_params dp = depth_params();
+  const bslam_buffer2d surfels = surfels_->ToPod(), active = active_surfels_->ToPod();
+  u32 surfel_count = surfel_count_;
+  for (u32 id : keyframe_ids) {
+    const auto& kf = keyframes_[id];
+    if (!kf) continue;
+    const bslam_keyframe_view view = kf->view();
+    Check(bslam_determine_supporting_surfels_and_merge(ctx_, stream, surfel_merge_dist_factor_, &depth_cam, &dp, &view, surfels_size_, &surfels,
+                                                       &surfel_count),
+          "bslam_determine_supporting_surfels_and_merge");
+  }
+  Lock();
+  surfel_count_ = surfel_count;
+  Unlock();
+  if (!keyframe_ids.empty()) {
+    u32 surfels_size = surfels_size_;
+    Check(bslam_compact_surfels(ctx_, stream, surfel_count_, &surfels_size, &surfels, &active), "bslam_compact_surfels");
+    Lock();
+    surfels_size_ = surfels_size;
+    Unlock();
+  }
+}
+
+// BS/direct_ba.cc:566-653
+void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates) {
+  u32 surfel_count = surfel_count_;
+  u32 surfels_size = surfels_size_;
+  const bslam_camera4f depth_cam = depth_camera_.pod();
+  const bslam_depth_params dp = depth_params();
+  const bslam_buffer2d surfels = surfels_->ToPod();
+  if (do_surfel_updates) {
+    for (const auto& kf : keyframes_) {
+      if (!kf || kf->last_active_in_ba_iteration() != ba_iteration_count_) continue;
+      const bslam_keyframe_view view = kf->view();
+      Check(bslam_determine_supporting_surfels_and_merge(ctx_, stream, surfel_merge_dist_factor_, &depth_cam, &dp, &view, surfels_size, &surfels,
+                                                         &surfel_count),
+            "bslam_determine_supporting_surfels_and_merge");
+    }
+  }
+  const std::vector<bslam_keyframe_view> views = KeyframeViews();
+  Check(bslam_delete_surfels_and_update_radii(ctx_, stream, GetMinObservationCount(), &depth_cam, &dp, static_cast<int>(views.size()), views.data(),
+                                              &surfel_count, surfels_size, &surfels),
+        "bslam_delete_surfels_and_update_radii");
+  Check(bslam_compact_surfels(ctx_, stream, surfel_count, &surfels_size, &surfels, nullptr), "bslam_compact_surfels");
+  Lock();
+  surfels_size_ = surfels_size;
+  surfel_count_ = surfel_count;
+  Unlock();
+}
+
 void DirectBA::SetSurfels(hipStream_t stream, const float* host_rows, size_t host_pitch_bytes, u32 count) {
   if (count > static_cast<u32>(surfels_->width())) throw std::invalid_argument("SetSurfels: count exceeds max_surfel_count");
   if (count > 0) {
@@ -325,9 +403,6 @@ void DirectBA::BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsi
   if (timer) throw std::invalid_argument("Timer objects are not supported; pass nullptr");
   if (optimize_depth_intrinsics && !use_depth_residuals_) optimize_depth_intrinsics = false;      // BS/direct_ba.cc:427-430
   if (optimize_color_intrinsics && !use_descriptor_residuals_) optimize_color_intrinsics = false; // :431-434
-  if (do_surfel_updates)
-    throw std::invalid_argument("do_surfel_updates: surfel creation / merge / deletion / compaction are not part of the hot path "
-                                "(SURVEY.md 8f row 1); run BA with do_surfel_updates = false");
   HIP_OR_THROW(hipSetDevice(device_));
   if (use_pcg)
     BundleAdjustmentPCG(stream, optimize_depth_intrinsics, optimize_color_intrinsics, do_surfel_updates, optimize_poses, optimize_geometry,
@@ -341,7 +416,7 @@ void DirectBA::BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsi
 
 // BS/direct_ba_alternating.cc:285-738
 void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
-                                           bool /*do_surfel_updates*/, bool optimize_poses, bool optimize_geometry, int min_iterations,
+                                           bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,
                                            int max_iterations, int active_keyframe_window_start, int active_keyframe_window_end,
                                            bool increase_ba_iteration_count, int* num_iterations_done, bool* converged, double time_limit,
                                            std::function<bool(int)> progress_function) {
@@ -352,7 +427,11 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
   Lock();
   const int fixed_ba_iteration_count = ba_iteration_count_;
   Unlock();
-  if (!increase_ba_iteration_count && fixed_ba_iteration_count != last_ba_iteration_count_) last_ba_iteration_count_ = fixed_ba_iteration_count;
+  if (!increase_ba_iteration_count && fixed_ba_iteration_count != last_ba_iteration_count_) {   // :311-317
+    last_ba_iteration_count_ = fixed_ba_iteration_count;
+    if (scheme_end_tasks_) PerformBASchemeEndTasks(stream, do_surfel_updates);
+  }
+  std::vector<u32> keyframes_with_new_surfels;
 
   const bool fixed_active_keyframe_set = active_keyframe_window_start > 0 || active_keyframe_window_end > 0;
   const bool whole_window = active_keyframe_window_start == 0 && active_keyframe_window_end == static_cast<int>(keyframes_.size()) - 1;
@@ -377,16 +456,37 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       Unlock();
     }
 
+    // --- SURFEL CREATION (:396-431) ---
+    keyframes_with_new_surfels.clear();
+    if (surfels_size_ != surfel_count_) throw std::logic_error("surfels_size_ != surfel_count_ at the start of a BA iteration");
+    const u32 old_surfels_size = surfels_size_;
+    if (optimize_geometry && do_surfel_updates) {
+      Lock();
+      for (const auto& kf : keyframes_) {
+        if (!kf) continue;
+        if (kf->activation() == Keyframe::Activation::kActive && kf->last_active_in_ba_iteration() != fixed_ba_iteration_count) {
+          kf->SetLastActiveInBAIteration(fixed_ba_iteration_count);
+          keyframes_with_new_surfels.push_back(static_cast<u32>(kf->id()));
+        } else if (kf->activation() == Keyframe::Activation::kCovisibleActive && kf->last_covis_in_ba_iteration() != fixed_ba_iteration_count) {
+          kf->SetLastCovisInBAIteration(fixed_ba_iteration_count);
+        }
+      }
+      Unlock();
+      for (u32 id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[id]);
+    }
+
     const bslam_depth_params dp = depth_params();
     std::vector<bslam_keyframe_view> views = KeyframeViews();
     const int K = static_cast<int>(views.size());
 
     // --- SURFEL ACTIVATION (:433-452) ---
     HIP_OR_THROW(hipEventRecord(ev_[0], stream));
+    if (optimize_geometry && surfels_size_ > old_surfels_size)
+      HIP_OR_THROW(hipMemsetAsync(active_surfels_->address() + old_surfels_size, BSLAM_SURFEL_ACTIVE_FLAG, (surfels_size_ - old_surfels_size) * sizeof(u8), stream));
     if (!whole_window) {
-      HIP_OR_THROW(hipMemsetAsync(active_surfels_->address(), BSLAM_SURFEL_ACTIVE_FLAG, surfels_size_ * sizeof(u8), stream));
+      HIP_OR_THROW(hipMemsetAsync(active_surfels_->address(), BSLAM_SURFEL_ACTIVE_FLAG, old_surfels_size * sizeof(u8), stream));
     } else {
-      Check(bslam_update_surfel_activation(ctx_, stream, &depth_cam, &dp, K, views.data(), surfels_size_, &surfels, &active), "bslam_update_surfel_activation");
+      Check(bslam_update_surfel_activation(ctx_, stream, &depth_cam, &dp, K, views.data(), old_surfels_size, &surfels, &active), "bslam_update_surfel_activation");
     }
     HIP_OR_THROW(hipEventRecord(ev_[1], stream));
 
@@ -398,6 +498,9 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
             "bslam_optimize_geometry_iteration");
       HIP_OR_THROW(hipEventRecord(ev_[3], stream));
     }
+
+    // --- SURFEL MERGE + COMPACTION (:486-533) ---
+    if (do_surfel_updates) MergeAndCompact(stream, keyframes_with_new_surfels);
 
     // --- POSE OPTIMIZATION (:543-577) ---
     size_t num_converged = 0;
@@ -491,11 +594,14 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     Unlock();
   }
 
-  if (increase_ba_iteration_count) ++ba_iteration_count_;   // PerformBASchemeEndTasks (surfel lifecycle) is out of scope
+  if (increase_ba_iteration_count) {   // :728-733
+    if (scheme_end_tasks_) PerformBASchemeEndTasks(stream, do_surfel_updates);
+    ++ba_iteration_count_;
+  }
 }
 
 // BS/direct_ba_pcg.cc:43-819
-void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics, bool /*do_surfel_updates*/,
+void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics, bool do_surfel_updates,
                                    bool optimize_poses, bool optimize_geometry, int min_iterations, int max_iterations,
                                    int max_inner_iterations, int max_keyframe_count, int /*active_keyframe_window_start*/,
                                    int /*active_keyframe_window_end*/, bool increase_ba_iteration_count, int* num_iterations_done,
@@ -507,14 +613,31 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
   if (keyframes_.empty()) return;
   if (static_cast<int>(keyframes_.size()) > max_keyframe_count) throw std::invalid_argument("keyframe count exceeds pcg_max_keyframes");
   const auto t_start = std::chrono::steady_clock::now();
-  if (!increase_ba_iteration_count && ba_iteration_count_ != last_ba_iteration_count_) last_ba_iteration_count_ = ba_iteration_count_;
+  if (!increase_ba_iteration_count && ba_iteration_count_ != last_ba_iteration_count_) {   // :155-161
+    last_ba_iteration_count_ = ba_iteration_count_;
+    if (scheme_end_tasks_) PerformBASchemeEndTasks(stream, do_surfel_updates);
+  }
 
   const bslam_buffer2d surfels = surfels_->ToPod(), active = active_surfels_->ToPod();
   const int K = static_cast<int>(keyframes_.size());
+  std::vector<u32> keyframes_with_new_surfels;
 
   for (int iteration = 0; iteration < max_iterations; ++iteration) {
     if (progress_function && !progress_function(iteration)) break;
     if (num_iterations_done) ++*num_iterations_done;
+
+    keyframes_with_new_surfels.clear();
+    if (optimize_geometry && do_surfel_updates) {   // :184-205
+      for (const auto& kf : keyframes_) {
+        if (kf->activation() == Keyframe::Activation::kActive && kf->last_active_in_ba_iteration() != ba_iteration_count_) {
+          kf->SetLastActiveInBAIteration(ba_iteration_count_);
+          CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, kf);
+          keyframes_with_new_surfels.push_back(static_cast<u32>(kf->id()));
+        } else if (kf->activation() == Keyframe::Activation::kCovisibleActive && kf->last_covis_in_ba_iteration() != ba_iteration_count_) {
+          kf->SetLastCovisInBAIteration(ba_iteration_count_);
+        }
+      }
+    }
 
     const bslam_camera4f color_cam = color_camera_.pod(), depth_cam = depth_camera_.pod();
     bslam_depth_params dp = depth_params();
@@ -634,6 +757,8 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       color_camera_ = PinholeCamera4f(color_camera_.width(), color_camera_.height(), np);
     }
 
+    if (do_surfel_updates) MergeAndCompact(stream, keyframes_with_new_surfels);   // :651-690
+
     if (timings_stream_) {
       HIP_OR_THROW(hipStreamSynchronize(stream));
       float ms = 0.f;
@@ -653,7 +778,12 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       if (elapsed > time_limit) break;
     }
   }
-  if (increase_ba_iteration_count) ++ba_iteration_count_;
+  if (increase_ba_iteration_count) {   // :764-773
+    if (scheme_end_tasks_) PerformBASchemeEndTasks(stream, do_surfel_updates);
+    ++ba_iteration_count_;
+  } else if (do_surfel_updates) {      // :775-815
+    MergeAndCompact(stream, keyframes_with_new_surfels);
+  }
 }
 
 }  // namespace bslam_host

@@ -179,6 +179,11 @@ class DirectBA {
   // one launch per Gauss-Newton iteration (bslam_estimate_frame_poses_batched); false = the
   // reference's sequential EstimateFramePose calls.
   void SetBatchedPoseOptimization(bool enable) { batched_pose_optimization_ = enable; }
+  // PerformBASchemeEndTasks (merge / delete / radius update / compaction at the end of a BA scheme) is on as in the
+  // reference; switching it off keeps the surfel set fixed across BundleAdjustment calls (parity tests against plain loops).
+  void SetSchemeEndTasks(bool enable) { scheme_end_tasks_ = enable; }
+  // DirectBA::CreateSurfelsForKeyframe (BS/direct_ba.h:118-121)
+  void CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const std::shared_ptr<Keyframe>& keyframe);
   // The reference picks the PCG gauge keyframe with rand() % K (BS/direct_ba_pcg.cc:328); a fixed
   // id >= 0 makes runs reproducible.
   void SetPCGGaugeKeyframe(int id) { fixed_gauge_keyframe_ = id; }
@@ -228,6 +233,11 @@ class DirectBA {
   void DetermineNewKeyframeCoVisibility(const std::shared_ptr<Keyframe>& new_keyframe);   // BS/direct_ba.cc:231-249
   void DetermineCovisibleActiveKeyframes();                                               // BS/direct_ba.cc:548-564
   std::vector<bslam_keyframe_view> KeyframeViews() const;
+  // Merge for the keyframes last active in this BA iteration, DeleteSurfelsAndUpdateRadii, Compact (BS/direct_ba.cc:566-653)
+  void PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates);
+  // DetermineSupportingSurfelsAndMergeSurfelsCUDA for the given keyframes, then CompactSurfelsCUDA incl. the active flags
+  // (BS/direct_ba_alternating.cc:486-533)
+  void MergeAndCompact(hipStream_t stream, const std::vector<u32>& keyframe_ids);
   void Check(int rc, const char* what) const;
 
   bslam_context* ctx_ = nullptr;
@@ -250,6 +260,7 @@ class DirectBA {
   // PCG vectors, allocated lazily (BS/direct_ba_pcg.cc:255-268)
   std::unique_ptr<DeviceBuffer<float>> pcg_r_, pcg_M_, pcg_delta_, pcg_g_, pcg_p_, pcg_scalars_;
   bool batched_pose_optimization_ = true;
+  bool scheme_end_tasks_ = true;
   int fixed_gauge_keyframe_ = -1;
   std::ostream* timings_stream_ = nullptr;
   bslam_allreduce_fn allreduce_ = nullptr;

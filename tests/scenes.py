@@ -267,7 +267,7 @@ def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, ma
 
 
 def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False,
-                    photometric=False):
+                    photometric=False, distortion=None, create_surfels=True):
     """Scene of {Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual
     (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-560): 20 random planes rendered
     from `num_keyframes` poses global_T_0 * exp(xi) (:286-296), undistorted depth, cell size 2; surfels
@@ -275,7 +275,10 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
     observation count, :516; creation is unfiltered here.)
     photometric=True gives the scene of {Alternating,PCG}IntrinsicsOptimizationWithPhotometricResidual
     (BS/test/test_intrinsics_optimization_photometric_residual.cc:25-160): border pixels keep their depth,
-    the colour is a world-space sinusoid texture (:50-53), descriptor residuals only."""
+    the colour is a world-space sinusoid texture (:50-53), descriptor residuals only.
+    distortion=(a, cfactor) distorts the rendered depth like TestDepthDeformationOptimizationWithGeometricResidual
+    (:111-125: the inverse of the depth deformation model through the Lambert W function); create_surfels=False
+    leaves surfel creation to the BA under test (do_surfel_updates)."""
     rng = np.random.default_rng(seed)
     cam = reference_test_camera(width, height)
     raw_to_float_depth = np.float32(1.0 / 1000)
@@ -299,6 +302,12 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
             upd = (z > 0) & ((best == 0) | (z < best))
             best = np.where(upd, z, best)
         depth = np.full((height, width), 65535, np.uint16)
+        if distortion is not None:
+            from scipy.special import lambertw
+            ta, tc = float(distortion[0]), float(distortion[1])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                wv = lambertw(-ta * tc * np.exp(-ta / best)).real
+                best = np.where(best == 0, 0.0, np.float32(1.0) / ((ta + best * wv) / (ta * best)).astype(np.float32))
         inner = np.minimum(65535, best[1:-1, 1:-1] / float(raw_to_float_depth) + 0.5)
         depth[1:-1, 1:-1] = np.where(best[1:-1, 1:-1] == 0, 65535, inner).astype(np.uint16)
         rgb = np.zeros((height, width, 3), np.uint8)
@@ -313,5 +322,6 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
             col = np.stack([chan(g[..., 0], g[..., 1]), chan(g[..., 1], g[..., 2]), chan(g[..., 2], g[..., 0])], axis=-1)
             rgb = np.where((best > 0)[..., None], col, 0).astype(np.uint8)
         kf = scene.add_keyframe_from_images(depth, rgb, T)
-        scene.create_surfels_for_keyframe(kf)
+        if create_surfels:
+            scene.create_surfels_for_keyframe(kf)
     return scene

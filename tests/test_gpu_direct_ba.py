@@ -92,6 +92,48 @@ def test_geometry_optimization_with_photometric_residual(oracle, use_pcg):
         assert abs(oc - correct) <= 0.002 * (oc + of), (oc, of, correct, fails)
 
 
+def test_do_surfel_updates_lifecycle_through_the_host_loop(oracle):
+    """BundleAdjustment(do_surfel_updates = true): the BA creates (filtered), merges, deletes and compacts the surfels
+    itself (BS/direct_ba_alternating.cc:396-533, BS/direct_ba.cc:566-653).  Same geometry known-answer as above, but
+    starting without any surfel."""
+    scene, kf, new_depth = scenes.geometry_geometric_scene(seed=0)
+    scene.surfels_size = 0
+    ba = make_ba(scene, pcg_gauge_keyframe=0)
+    assert ba.surfels_size() == 0
+    for _ in range(10):
+        ba.BundleAdjustment(False, False, True, False, True, 10, 10, False, 0, 0, True)
+    n = ba.surfels_size()
+    assert n > 250000, n
+    surf = ba.GetSurfels(8)
+    assert not np.isnan(surf[0]).any()                       # compacted: no deleted surfel left
+    err = depth_check(scene, kf, new_depth, surf)
+    assert (err > 1e-4).sum() == 0, ((err > 1e-4).sum(), err.size)   # end-of-scheme deletion removes the never-associated ones
+
+
+@pytest.mark.parametrize("use_pcg", [False, True])
+def test_depth_deformation_optimization_with_geometric_residual(oracle, use_pcg):
+    """{Alternating,PCG}DepthDeformationOptimizationWithGeometricResidual
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:286-368): 12 keyframes of 20 planes whose depth is
+    distorted with a = 0.03, cfactor = 0.005; 400 (alternating) / 20 (PCG) BA calls with surfel updates, geometry and --
+    from the second call on -- depth intrinsics; bars |a - 0.03| < 1e-2 and |cfactor(50, 50) - 0.005| < 1e-3 (:361-365)."""
+    true_a, true_cf = 0.03, 0.005
+    scene = scenes.intrinsics_scene(12, seed=0, cell=2, max_surfels=1000 * 1000, distortion=(true_a, true_cf), create_surfels=False)
+    from badslam_amd.direct_ba import DirectBA
+    ba = DirectBA(scene.max_surfels, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, 0.8, 2, 2, 2,
+                  scene.color_camera, scene.depth_camera, 0, True, False)
+    ba.set_options(texture_mode=scene.tex_mode, pcg_gauge_keyframe=0)
+    for kf in scene.keyframes:
+        ba.AddKeyframe(kf.id, max(kf.min_depth, 1e-3), max(kf.max_depth, 1e-2), kf.depth, kf.normals, kf.radius, kf.color, kf.global_T_frame)
+    K = len(scene.keyframes)
+    for i in range(20 if use_pcg else 400):
+        ba.BundleAdjustment(i != 0, False, True, False, True, 1, 10, use_pcg, 0, K - 1, i != 0)
+    _, _, a = ba.intrinsics()
+    cf = ba.cfactor(scene.cfactor.shape)
+    assert ba.surfels_size() > 100000
+    assert abs(a - true_a) < 1e-2, a
+    assert abs(cf[50, 50] - true_cf) < 1e-3, cf[50, 50]
+
+
 def oracle_alternating_iteration(scene, covis):
     """One iteration of BS/direct_ba_alternating.cc:345-717 with the oracle's kernels
     (whole window, no surfel updates, sequential EstimateFramePose)."""
@@ -120,6 +162,7 @@ def oracle_alternating_iteration(scene, covis):
 
 @pytest.mark.parametrize("batched", [True, False])
 def test_alternating_ba_matches_oracle_loop(oracle, batched):
+    # (scheme end tasks off: the oracle loop below restates the iteration body only)
     scene = scenes.synthetic_scene(4, seed=41, use_depth_residuals=True, use_descriptor_residuals=False)
     rng = np.random.default_rng(4)
     n = scene.surfels_size
@@ -127,7 +170,7 @@ def test_alternating_ba_matches_oracle_loop(oracle, batched):
     for kf in scene.keyframes:
         x = np.concatenate([rng.uniform(-0.003, 0.003, 3), rng.uniform(-0.001, 0.001, 3)]).astype(np.float32)
         kf.global_T_frame = bso.se3_mul(kf.global_T_frame, bso.se3_exp(x))
-    ba = make_ba(scene, batched_pose_optimization=batched)
+    ba = make_ba(scene, batched_pose_optimization=batched, scheme_end_tasks=False)
     covis = {kf.id: ba.keyframe_covisibility(kf.id) for kf in scene.keyframes}
     assert all(len(v) == len(scene.keyframes) - 1 for v in covis.values()), covis   # all frusta overlap in this scene
     # first iteration on its own: identical inputs on both sides -> integer outputs must be identical
@@ -222,19 +265,24 @@ def test_intrinsics_optimization_with_photometric_residual(oracle, use_pcg):
     from tests.test_oracle_known_answers import distorted_camera
     scene = scenes.intrinsics_scene(12, seed=0, cell=2, max_surfels=1000 * 1000, photometric=True)
     true = scene.color_camera
-    ba = make_ba(scene, pcg_gauge_keyframe=0)
     d = distorted_camera(true, 1.0)
-    ba.set_intrinsics([d.fx, d.fy, d.cx, d.cy], None, 0.0)
     if not use_pcg:
-        # the reference's schedule: 10 x 1 step, compared with the same 10 steps of the oracle
+        # the reference's schedule: 10 x 1 step, compared with the same 10 steps of the oracle (scheme-end
+        # deletion / radius update off: the oracle loop restates the intrinsics step only)
+        ba = make_ba(scene, pcg_gauge_keyframe=0, scheme_end_tasks=False)
+        ba.set_intrinsics([d.fx, d.fy, d.cx, d.cy], None, 0.0)
         for i in range(10):
             ba.BundleAdjustment(False, True, False, False, False, 1, 10, False, 0, len(scene.keyframes) - 1, i != 0)
         cc, _, _ = ba.intrinsics()
+        true_cam = scene.color_camera
         scene.color_camera = d
         for i in range(10):
             scene.optimize_intrinsics(False, True)
         oc = scene.color_camera
+        scene.color_camera = true_cam
         assert np.allclose(cc, [oc.fx, oc.fy, oc.cx, oc.cy], rtol=2e-4), (cc, oc.fx, oc.fy, oc.cx, oc.cy)
+    ba = make_ba(scene, pcg_gauge_keyframe=0)
+    ba.set_intrinsics([d.fx, d.fy, d.cx, d.cy], None, 0.0)
     for i in range(10):
         ba.BundleAdjustment(False, True, False, False, False, 10, 10, use_pcg, 0, len(scene.keyframes) - 1, True)
     cc, _, _ = ba.intrinsics()

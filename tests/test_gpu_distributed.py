@@ -101,7 +101,7 @@ def _run_ba(scene, lo, hi, use_pcg, depth_intr, hook=None):
     from badslam_amd.direct_ba import DirectBA
     ba = DirectBA(max(1, hi - lo), scene.raw_to_float_depth, scene.baseline_fx, scene.cell, 0.8, 1, 1, 1,
                   scene.color_camera, scene.depth_camera, 0, scene.use_depth_residuals, scene.use_descriptor_residuals)
-    ba.set_options(pcg_gauge_keyframe=0, texture_mode=scene.tex_mode)
+    ba.set_options(pcg_gauge_keyframe=0, texture_mode=scene.tex_mode, scheme_end_tasks=False)   # keep the shard's surfel set fixed
     if hook is not None:
         ba.set_allreduce(hook.callback)
     for kf in scene.keyframes:
