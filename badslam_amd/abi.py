@@ -96,6 +96,13 @@ SIGNATURES = {
                                                    P(C.c_uint32)]),
     "bslam_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(Camera4f), P(DepthParams), C.c_int, P(KeyframeView),
                                                        P(C.c_uint32), C.c_uint32, P(Buffer2D)]),
+    "bslam_compute_brightness": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), P(Buffer2D)]),
+    "bslam_bilateral_filter_and_depth_cutoff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint16, C.c_float,
+                                                         P(Buffer2D), P(Buffer2D)]),
+    "bslam_compute_normals": (C.c_int, [C.c_void_p, C.c_void_p, P(Camera4f), P(DepthParams), P(Buffer2D), P(Buffer2D), P(Buffer2D)]),
+    "bslam_compute_point_radii_and_remove_isolated_pixels": (C.c_int, [C.c_void_p, C.c_void_p, P(Camera4f), C.c_float, P(Buffer2D), P(Buffer2D),
+                                                                      P(Buffer2D)]),
+    "bslam_compute_min_max_depth": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), C.c_float, P(C.c_float), P(C.c_float)]),
     "bslam_compact_surfels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32), P(Buffer2D), P(Buffer2D)]),
     "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -12,6 +12,7 @@
 #include "intrinsics_kernels.hpp"
 #include "pcg_kernels.hpp"
 #include "lifecycle_kernels.hpp"
+#include "preprocess_kernels.hpp"
 #include "pose_kernels.hpp"
 
 namespace bslam {
@@ -757,3 +758,4 @@ int bslam_debug_pose_residuals(
 #include "intrinsics_abi.inc"
 #include "pcg_abi.inc"
 #include "lifecycle_abi.inc"
+#include "preprocess_abi.inc"

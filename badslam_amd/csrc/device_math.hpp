@@ -94,11 +94,30 @@ __device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3
   return f2{fx * (p.x / p.z) + cx, fy * (p.y / p.z) + cy};
 }
 
-// BS/util.cuh:46-53.  expf(-a * inv_depth) is exactly 1 for a == 0 (the default, no depth
-// deformation), so that case skips the transcendental without changing a bit.
+// exp(x) from plain fp32 multiplies and adds (Cephes expf: Cody-Waite reduction by ln 2, degree-5 polynomial,
+// ~1 ulp).  The device library's expf and the CPU's libm do not agree to the last bit; the depth deformation
+// exp(-a / d) feeds the association predicate, whose integer outputs are compared bit for bit with the oracle, so
+// both sides evaluate this same sequence.  (The reference evaluates exp under -use_fast_math.)
+__device__ __forceinline__ float det_expf(float x) {
+  if (x < -87.0f) return 0.f;
+  if (x > 88.0f) return __uint_as_float(0x7f800000u);
+  const float n = floorf(x * 1.44269504088896341f + 0.5f);
+  const float r = (x - n * 0.693359375f) - n * -2.12194440e-4f;
+  float p = 1.9875691500e-4f;
+  p = p * r + 1.3981999507e-3f;
+  p = p * r + 8.3334519073e-3f;
+  p = p * r + 4.1665795894e-2f;
+  p = p * r + 1.6666665459e-1f;
+  p = p * r + 5.0000001201e-1f;
+  const float y = (p * r) * r + r + 1.0f;
+  return y * __uint_as_float((uint32_t)((int32_t)n + 127) << 23);
+}
+
+// BS/util.cuh:46-53.  exp(-a * inv_depth) is exactly 1 for a == 0 (the default, no depth
+// deformation), so that case skips the evaluation without changing a bit.
 __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint32_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * (float)measured_depth);
-  const float e = (a == 0.f) ? 1.0f : expf(-a * inv_depth);
+  const float e = (a == 0.f) ? 1.0f : det_expf(-a * inv_depth);
   return 1.f / (inv_depth + cfactor * e);
 }
 

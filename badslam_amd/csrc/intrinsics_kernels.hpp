@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
         const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
         const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)p.raw_depth);
-        const float exp_inv_depth = expf(-c.a * raw_inv_depth);
+        const float exp_inv_depth = det_expf(-c.a * raw_inv_depth);
         const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
         if (fabsf(corrected_inv_depth) > 1e-4f) {
           const f3 ln = p.n_local;

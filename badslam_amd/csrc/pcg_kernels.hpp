@@ -76,7 +76,7 @@ __device__ __forceinline__ DepthIntrinsicsTerms depth_intrinsics_terms(const Cam
   const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
   const uint32_t measured = p.raw_depth;
   const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)measured);
-  const float exp_inv_depth = expf(-c.a * raw_inv_depth);
+  const float exp_inv_depth = det_expf(-c.a * raw_inv_depth);
   const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
   t.valid = !(fabsf(corrected_inv_depth) < 1e-4f);
   const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);

@@ -32,6 +32,8 @@ def host_lib():
                              f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.bsh_destroy.argtypes = [C.c_void_p]
     L.bsh_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, u16p, u16p, u16p, u8p, f32p]
+    L.bsh_add_keyframe_from_images.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u16p, u8p, f32p]
+    L.bsh_get_keyframe_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p, u16p, u16p, u8p, f32p]
     L.bsh_set_surfels.argtypes = [C.c_void_p, C.c_void_p, f32p, C.c_size_t, C.c_uint32]
     L.bsh_get_surfels.argtypes = [C.c_void_p, C.c_void_p, f32p, C.c_size_t, C.c_int]
     L.bsh_get_active_surfels.argtypes = [C.c_void_p, C.c_void_p, u8p]
@@ -114,6 +116,22 @@ class DirectBA:
         col = np.ascontiguousarray(color, np.uint8)
         return self._check(self.L.bsh_add_keyframe(self._ba, self.stream, frame_index, min_depth, max_depth, u16(depth), u16(normals), u16(radius),
                                                    col.ctypes.data_as(C.POINTER(C.c_uint8)), _f(p)))
+
+    def AddKeyframeFromImages(self, frame_index, depth_u16, rgb_u8, global_T_frame):
+        """Keyframe(stream, frame_index, depth_params, depth_camera, depth_image, color_image, pose) + AddKeyframe: the raw
+        images are preprocessed on the device (BS/keyframe.cc:82-161)."""
+        d = np.ascontiguousarray(depth_u16, np.uint16)
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        return self._check(self.L.bsh_add_keyframe_from_images(self._ba, self.stream, frame_index, d.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                               rgb.ctypes.data_as(C.POINTER(C.c_uint8)), _f(pose7(global_T_frame))))
+
+    def keyframe_images(self, kf_id, height, width):
+        u16 = lambda: np.zeros((height, width), np.uint16)
+        depth, normals, radius, color, mm = u16(), u16(), u16(), np.zeros((height, width, 4), np.uint8), np.zeros(2, np.float32)
+        p16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint16))
+        self._check(self.L.bsh_get_keyframe_images(self._ba, self.stream, kf_id, p16(depth), p16(normals), p16(radius),
+                                                   color.ctypes.data_as(C.POINTER(C.c_uint8)), _f(mm)))
+        return depth, normals, radius, color, float(mm[0]), float(mm[1])
 
     def SetSurfels(self, rows, count):
         rows = np.ascontiguousarray(rows, np.float32)

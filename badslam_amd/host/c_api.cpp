@@ -99,6 +99,28 @@ int bsh_upload_keyframe_normals(void* ba, void* stream, int id, const uint16_t* 
   });
 }
 
+int bsh_add_keyframe_from_images(void* ba_, void* stream, uint32_t frame_index, const uint16_t* depth, const uint8_t* rgb, const float* pose7) {
+  DirectBA* ba = static_cast<DirectBA*>(ba_);
+  try {
+    return ba->AddKeyframeFromImages(static_cast<hipStream_t>(stream), frame_index, depth, rgb, pose_from7(pose7))->id();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int bsh_get_keyframe_images(void* ba, void* stream, int id, uint16_t* depth, uint16_t* normals, uint16_t* radius, uint8_t* color, float* min_max) {
+  BSH_TRY({
+    const auto& kf = static_cast<DirectBA*>(ba)->keyframes().at(id);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t w = static_cast<size_t>(kf->depth_buffer().width());
+    kf->depth_buffer().Download(s, depth, w * 2);
+    kf->normals_buffer().Download(s, normals, w * 2);
+    kf->radius_buffer().Download(s, radius, w * 2);
+    kf->color_buffer().Download(s, reinterpret_cast<uchar4_t*>(color), static_cast<size_t>(kf->color_buffer().width()) * 4);
+    min_max[0] = kf->min_depth();
+    min_max[1] = kf->max_depth();
+  });
+}
 int bsh_set_scheme_end_tasks(void* ba, int enable) { BSH_TRY(static_cast<DirectBA*>(ba)->SetSchemeEndTasks(enable != 0)); }
 int bsh_create_surfels_for_keyframe(void* ba, void* stream, int filter_new_surfels, int keyframe_id) {
   BSH_TRY({

@@ -63,6 +63,32 @@ Keyframe::Keyframe(hipStream_t stream, u32 frame_index, float min_depth, float m
   set_global_T_frame(global_T_frame);
 }
 
+Keyframe::Keyframe(bslam_context* ctx, hipStream_t stream, u32 frame_index, const bslam_depth_params& depth_params, const bslam_camera4f& depth_camera,
+                   const u16* depth_image, int color_width, int color_height, const u8* rgb_image, const SE3f& global_T_frame)
+    : frame_index_(frame_index), min_depth_(0.f), max_depth_(0.f),
+      depth_(depth_camera.height, depth_camera.width), normals_(depth_camera.height, depth_camera.width),
+      radius_(depth_camera.height, depth_camera.width), color_(color_height, color_width) {
+  const int w = depth_camera.width, h = depth_camera.height;
+  auto check = [](int rc, const char* what) { if (rc != BSLAM_OK) throw std::runtime_error(std::string(what) + ": " + bslam_last_error()); };
+  DeviceBuffer<u8> rgb(color_height, color_width * 3);
+  rgb.Upload(stream, rgb_image, static_cast<size_t>(color_width) * 3);
+  bslam_buffer2d rgb_pod = rgb.ToPod();
+  rgb_pod.width = color_width;   // 3 bytes per pixel
+  const bslam_buffer2d color_pod = color_.ToPod();
+  check(bslam_compute_brightness(ctx, stream, &rgb_pod, &color_pod), "bslam_compute_brightness");
+  DeviceBuffer<u16> raw(h, w), stage1(h, w);
+  raw.Upload(stream, depth_image, static_cast<size_t>(w) * sizeof(u16));
+  const bslam_buffer2d raw_pod = raw.ToPod(), stage1_pod = stage1.ToPod(), normals_pod = normals_.ToPod(), radius_pod = radius_.ToPod(),
+                       depth_pod = depth_.ToPod();
+  check(bslam_compute_normals(ctx, stream, &depth_camera, &depth_params, &raw_pod, &stage1_pod, &normals_pod), "bslam_compute_normals");
+  check(bslam_compute_point_radii_and_remove_isolated_pixels(ctx, stream, &depth_camera, depth_params.raw_to_float_depth, &stage1_pod, &radius_pod,
+                                                             &depth_pod),
+        "bslam_compute_point_radii_and_remove_isolated_pixels");
+  check(bslam_compute_min_max_depth(ctx, stream, &stage1_pod, depth_params.raw_to_float_depth, &min_depth_, &max_depth_), "bslam_compute_min_max_depth");
+  HIP_OR_THROW(hipStreamSynchronize(stream));   // the temporaries die here
+  set_global_T_frame(global_T_frame);
+}
+
 bslam_keyframe_view Keyframe::view() const {
   bslam_keyframe_view v;
   v.depth = depth_.ToPod();
@@ -259,6 +285,16 @@ std::vector<bslam_keyframe_view> DirectBA::KeyframeViews() const {
   v.reserve(keyframes_.size());
   for (const auto& kf : keyframes_) if (kf) v.push_back(kf->view());
   return v;
+}
+
+std::shared_ptr<Keyframe> DirectBA::AddKeyframeFromImages(hipStream_t stream, u32 frame_index, const u16* depth_image, const u8* rgb_image,
+                                                          const SE3f& global_T_frame) {
+  const bslam_depth_params dp = depth_params();
+  const bslam_camera4f depth_cam = depth_camera_.pod();
+  auto kf = std::make_shared<Keyframe>(ctx_, stream, frame_index, dp, depth_cam, depth_image, color_camera_.width(), color_camera_.height(), rgb_image,
+                                       global_T_frame);
+  AddKeyframe(kf);
+  return kf;
 }
 
 // BS/direct_ba.cc:340-405

@@ -86,6 +86,12 @@ class Keyframe {
   Keyframe(hipStream_t stream, u32 frame_index, float min_depth, float max_depth, int width, int height,
            const u16* depth, const u16* normals, const u16* radius, const uchar4_t* color, const SE3f& global_T_frame);
 
+  // Mirrors the reference constructor from raw images (BS/keyframe.cc:82-161): uploads the u16 depth and the
+  // 3-byte rgb image (HOST arrays) and runs ComputeBrightness, ComputeNormals, ComputePointRadiiAndRemoveIsolatedPixels
+  // and ComputeMinMaxDepth through the C ABI of `ctx`.
+  Keyframe(bslam_context* ctx, hipStream_t stream, u32 frame_index, const bslam_depth_params& depth_params, const bslam_camera4f& depth_camera,
+           const u16* depth_image, int color_width, int color_height, const u8* rgb_image, const SE3f& global_T_frame);
+
   const DeviceBuffer<u16>& depth_buffer() const { return depth_; }
   const DeviceBuffer<u16>& normals_buffer() const { return normals_; }
   const DeviceBuffer<u16>& radius_buffer() const { return radius_; }
@@ -184,6 +190,9 @@ class DirectBA {
   void SetSchemeEndTasks(bool enable) { scheme_end_tasks_ = enable; }
   // DirectBA::CreateSurfelsForKeyframe (BS/direct_ba.h:118-121)
   void CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const std::shared_ptr<Keyframe>& keyframe);
+  // new Keyframe(stream, frame_index, depth_params(), depth_camera(), depth_image, color_image, pose) + AddKeyframe
+  // (the idiom of the reference's tests, e.g. BS/test/test_pose_optimization_geometric_residual.cc:108-118)
+  std::shared_ptr<Keyframe> AddKeyframeFromImages(hipStream_t stream, u32 frame_index, const u16* depth_image, const u8* rgb_image, const SE3f& global_T_frame);
   // The reference picks the PCG gauge keyframe with rand() % K (BS/direct_ba_pcg.cc:328); a fixed
   // id >= 0 makes runs reproducible.
   void SetPCGGaugeKeyframe(int id) { fixed_gauge_keyframe_ = id; }

@@ -375,6 +375,41 @@ int bslam_compact_surfels(
     bslam_context* ctx, void* stream, uint32_t surfel_count, uint32_t* surfels_size,
     const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels);
 
+/* ------------------------------------------------------------------------- */
+/* Keyframe preprocessing producers                          */
+/* ------------------------------------------------------------------------- */
+/* These write the u16 / half / uchar4 keyframe images the bundle adjuster reads.  Buffers are device
+ * memory; input and output of one call must not alias. */
+
+/* Replaces ComputeBrightnessCUDA (BS/cuda_image_processing.cuh, kernel BS/cuda_image_processing.cu:165-194):
+ * rgb_buffer has 3 bytes per pixel, color_buffer 4 (r, g, b, luma). */
+int bslam_compute_brightness(bslam_context* ctx, void* stream,
+                             const bslam_buffer2d* rgb_buffer, const bslam_buffer2d* color_buffer);
+
+/* Replaces BilateralFilteringAndDepthCutoffCUDA (BS/cuda_depth_processing.cu:42-132); the exponential is
+ * evaluated with the library's deterministic exp (the reference uses -use_fast_math). */
+int bslam_bilateral_filter_and_depth_cutoff(
+    bslam_context* ctx, void* stream, float sigma_xy, float sigma_value, float radius_factor,
+    uint16_t max_depth, float raw_to_float_depth,
+    const bslam_buffer2d* input_depth, const bslam_buffer2d* output_depth);
+
+/* Replaces ComputeNormalsCUDA (BS/cuda_depth_processing.cu:134-276). */
+int bslam_compute_normals(
+    bslam_context* ctx, void* stream, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params, const bslam_buffer2d* input_depth,
+    const bslam_buffer2d* output_depth, const bslam_buffer2d* normals_buffer);
+
+/* Replaces ComputePointRadiiAndRemoveIsolatedPixelsCUDA (BS/cuda_depth_processing.cu:278-380). */
+int bslam_compute_point_radii_and_remove_isolated_pixels(
+    bslam_context* ctx, void* stream, const bslam_camera4f* depth_camera, float raw_to_float_depth,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* radius_buffer,
+    const bslam_buffer2d* out_depth);
+
+/* Replaces ComputeMinMaxDepthCUDA (BS/cuda_depth_processing.cu:382-465); results valid on return. */
+int bslam_compute_min_max_depth(
+    bslam_context* ctx, void* stream, const bslam_buffer2d* depth_buffer, float raw_to_float_depth,
+    float* min_depth, float* max_depth);
+
 /* Multi-GPU (surfel-sharded) runs of the PCG and intrinsics entry points: every rank holds its own
  * surfel shard and the full keyframe list; `allreduce` sums a device buffer of floats in place across
  * ranks (ordered after prior work on `stream`, e.g. RCCL ncclAllReduce on that stream).  It is

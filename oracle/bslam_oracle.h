@@ -147,6 +147,15 @@ void bso_compute_brightness(int width, int height, const uint8_t* rgb, const bsl
  * constructor chains them (BS/keyframe.cc:116-138): in_depth -> kf depth / normals /
  * radius (all u16, caller-allocated).  Returns min/max metric depth of valid pixels
  * in *min_depth / *max_depth (BS/cuda_depth_processing.cu:391-465). */
+/* keyframe preprocessing producers, BS/cuda_depth_processing.cu */
+void bso_bilateral_filter_and_depth_cutoff(float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                                           float raw_to_float_depth, const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth);
+void bso_compute_normals(const bslam_camera4f* depth_camera, const bslam_depth_params* dp, const bslam_buffer2d* in_depth,
+                         const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals);
+void bso_compute_point_radii_and_remove_isolated_pixels(const bslam_camera4f* depth_camera, float raw_to_float_depth,
+                                                        const bslam_buffer2d* in_depth, const bslam_buffer2d* out_radius,
+                                                        const bslam_buffer2d* out_depth);
+void bso_compute_min_max_depth(const bslam_buffer2d* depth, float raw_to_float_depth, float* min_depth, float* max_depth);
 void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
                           const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth,
                           const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,

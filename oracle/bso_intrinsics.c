@@ -55,7 +55,7 @@ void bso_optimize_intrinsics(
           const int sparse_px = r.px / dp->sparse_surfel_cell_size, sparse_py = r.py / dp->sparse_surfel_cell_size;
           const float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
           const float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-          const float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+          const float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
           const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
           if (fabsf(corrected_inv_depth) > 1e-4f) {
             const bso_f3 ln = bso_rotate34(&kf->frame_T_global, r.surfel_normal);

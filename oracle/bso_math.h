@@ -11,7 +11,7 @@
  *
  * Known, documented deviations from what the CUDA build computes:
  *   - the reference is compiled with -use_fast_math (approximate division / sqrtf /
- *     expf); this restatement uses IEEE division, sqrtf and libm expf;
+ *     expf); this restatement uses IEEE division, sqrtf and bso_expf (below);
  *   - tex2D() bilinear filtering is modelled in software (bso_tex_w below).
  */
 #ifndef BSO_MATH_H_
@@ -122,10 +122,31 @@ static inline int bso_depth_to_color_pxy(bso_f2 pxy, const bso_depth_to_color* d
   return out->x >= 0 && out->y >= 0 && bso_f2i(out->x) < d->width && bso_f2i(out->y) < d->height;
 }
 
+/* exp(x) from plain fp32 multiplies and adds (Cephes expf: Cody-Waite reduction by ln 2, degree-5 polynomial on
+ * |r| <= ln2 / 2, ~1 ulp), so that this oracle and the HIP kernels agree bit for bit; libm's and the device
+ * library's expf do not.  (The reference itself evaluates exp with -use_fast_math, i.e. ex2.approx.)  exp(0) = 1. */
+static inline float bso_expf(float x) {
+  if (x < -87.0f) return 0.f;
+  if (x > 88.0f) return INFINITY;
+  const float n = floorf(x * 1.44269504088896341f + 0.5f);
+  const float r = (x - n * 0.693359375f) - n * -2.12194440e-4f;
+  float p = 1.9875691500e-4f;
+  p = p * r + 1.3981999507e-3f;
+  p = p * r + 8.3334519073e-3f;
+  p = p * r + 4.1665795894e-2f;
+  p = p * r + 1.6666665459e-1f;
+  p = p * r + 5.0000001201e-1f;
+  const float y = (p * r) * r + r + 1.0f;
+  const uint32_t bits = (uint32_t)((int32_t)n + 127) << 23;
+  float two_n;
+  memcpy(&two_n, &bits, 4);
+  return y * two_n;
+}
+
 /* ---- BS/util.cuh:46-53 ------------------------------------------------------- */
 static inline float bso_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
-  return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
+  return 1.f / (inv_depth + cfactor * bso_expf(-a * inv_depth));
 }
 
 /* ---- BS/util.cuh:101-130 ----------------------------------------------------- */

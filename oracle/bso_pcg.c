@@ -82,7 +82,7 @@ static void pcg_init_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* c
         int sparse_py = r.py / dp->sparse_surfel_cell_size;
         float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
         float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-        float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+        float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
         float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
         if (fabsf(corrected_inv_depth) < 1e-4f) vis = 0;                    /* NOTE: stays false for the descriptor part too (:272) */
         float nx = bso_unproj_nx(&c->unproj, r.px);
@@ -232,7 +232,7 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
         int sparse_py = r.py / dp->sparse_surfel_cell_size;
         float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
         float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-        float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+        float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
         float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
         djv = !(fabsf(corrected_inv_depth) < 1e-4f);
         if (djv) {

@@ -75,18 +75,53 @@ float bso_half_to_float(uint16_t h) {
   return f;
 }
 
-void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
-                          const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth,
-                          const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,
-                          float* min_depth_out, float* max_depth_out) {
+/* BilateralFilteringAndDepthCutoffCUDAKernel BS/cuda_depth_processing.cu:42-100 (+ host wrapper :102-132) */
+void bso_bilateral_filter_and_depth_cutoff(float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                                           float raw_to_float_depth, const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth) {
+  const int w = out_depth->width, h = out_depth->height;
+  const float denom_xy = 2.0f * sigma_xy * sigma_xy, denom_value = 2.0f * sigma_value * sigma_value;
+  const int radius = (int)(radius_factor * sigma_xy + 0.5f);
+  const int radius_squared = radius * radius;
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      const uint16_t center_value = BSO_AT(uint16_t, in_depth, y, x);
+      if (center_value == 0 || center_value > max_depth) { BSO_AT(uint16_t, out_depth, y, x) = BSLAM_UNKNOWN_DEPTH; continue; }
+      const float inv_center_value = 1.0f / (raw_to_float_depth * center_value);
+      float sum = 0, weight = 0;
+      const int min_y = y - radius > 0 ? y - radius : 0, max_y = y + radius < h - 1 ? y + radius : h - 1;
+      const int min_x = x - radius > 0 ? x - radius : 0, max_x = x + radius < w - 1 ? x + radius : w - 1;
+      for (int sy = min_y; sy <= max_y; ++sy) {
+        const int dy = sy - y;
+        for (int sx = min_x; sx <= max_x; ++sx) {
+          const int dx = sx - x;
+          const int grid_distance_squared = dx * dx + dy * dy;
+          if (grid_distance_squared > radius_squared) continue;
+          const uint16_t sample = BSO_AT(uint16_t, in_depth, sy, sx);
+          if (sample == 0) continue;
+          const float inv_sample = 1.0f / (raw_to_float_depth * sample);
+          float value_distance_squared = inv_center_value - inv_sample;
+          value_distance_squared *= value_distance_squared;
+          const float wgt = bso_expf(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
+          sum += wgt * inv_sample;
+          weight += wgt;
+        }
+      }
+      if (weight == 0) { BSO_AT(uint16_t, out_depth, y, x) = BSLAM_UNKNOWN_DEPTH; continue; }
+      const float v = 1.0f / (raw_to_float_depth * sum / weight);
+      BSO_AT(uint16_t, out_depth, y, x) = (uint16_t)(v >= 65535.f ? 65535 : (v <= 0.f || v != v ? 0 : (int)v));   /* cvt.rzi.u16.f32 saturates */
+    }
+  }
+}
+
+/* ComputeNormalsCUDAKernel BS/cuda_depth_processing.cu:134-255 */
+void bso_compute_normals(const bslam_camera4f* depth_camera, const bslam_depth_params* dp, const bslam_buffer2d* in_depth,
+                         const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals) {
   const int w = in_depth->width, h = in_depth->height;
   bso_unprojector u = bso_make_unprojector(depth_camera);
   const int cell = dp->sparse_surfel_cell_size;
-  /* stage 1: ComputeNormalsCUDAKernel BS/cuda_depth_processing.cu:134-255 -> tmp depth + normals */
-  uint16_t* tmp = (uint16_t*)malloc((size_t)w * h * sizeof(uint16_t));
   for (int y = 0; y < h; ++y) {
     for (int x = 0; x < w; ++x) {
-      uint16_t* od = &tmp[(size_t)y * w + x];
+      uint16_t* od = &BSO_AT(uint16_t, out_depth, y, x);
       uint16_t* on = &BSO_AT(uint16_t, out_normals, y, x);
       const int kBorder = 1;
       if (x < kBorder || y < kBorder || x >= w - kBorder || y >= h - kBorder) {
@@ -141,31 +176,35 @@ void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_
       *od = c;
     }
   }
-  /* stage 2: ComputePointRadiiAndRemoveIsolatedPixelsCUDAKernel<4> BS/cuda_depth_processing.cu:286-357 */
-  float min_depth = INFINITY, max_depth = 0.f;
+}
+
+/* ComputePointRadiiAndRemoveIsolatedPixelsCUDAKernel<4> BS/cuda_depth_processing.cu:286-357.  in_depth is the
+ * output of bso_compute_normals (its 1-pixel border is invalid, so the 4-neighbourhood never leaves the image). */
+void bso_compute_point_radii_and_remove_isolated_pixels(const bslam_camera4f* depth_camera, float raw_to_float_depth,
+                                                        const bslam_buffer2d* in_depth, const bslam_buffer2d* out_radius,
+                                                        const bslam_buffer2d* out_depth) {
+  const int w = in_depth->width, h = in_depth->height;
+  bso_unprojector u = bso_make_unprojector(depth_camera);
   for (int y = 0; y < h; ++y) {
     for (int x = 0; x < w; ++x) {
-      const uint16_t d16 = tmp[(size_t)y * w + x];
+      const uint16_t d16 = BSO_AT(uint16_t, in_depth, y, x);
       if (d16 & BSLAM_INVALID_DEPTH_BIT) {
         BSO_AT(uint16_t, out_depth, y, x) = BSLAM_UNKNOWN_DEPTH;
         BSO_AT(uint16_t, out_radius, y, x) = 0;   /* the reference leaves it unwritten */
         continue;
       }
-      /* min/max over the stage-1 depth (BS/keyframe.cc:140-147, BS/cuda_depth_processing.cu:391-465) */
-      float dm = dp->raw_to_float_depth * d16;
-      if (dm < min_depth) min_depth = dm;
-      if (dm > max_depth) max_depth = dm;
-      float depth = dp->raw_to_float_depth * d16;
+      float depth = raw_to_float_depth * d16;
       bso_f3 local = bso_make3(depth * (u.fx_inv * x + u.cx_inv), depth * (u.fy_inv * y + u.cy_inv), depth);
       int neighbor_count = 0;
       float min_sq = INFINITY;
       for (int dy = y - 1; dy < y + 2; ++dy) {
         for (int dx = x - 1; dx < x + 2; ++dx) {
           if ((dx != x && dy != y) || (dx == x && dy == y)) continue;
-          uint16_t dd = tmp[(size_t)dy * w + dx];   /* interior only: stage 1 invalidates the 1-pixel border */
+          if (dx < 0 || dy < 0 || dx >= w || dy >= h) continue;     /* only reachable if the input has a valid border */
+          uint16_t dd = BSO_AT(uint16_t, in_depth, dy, dx);
           if (dd & BSLAM_INVALID_DEPTH_BIT) continue;
           ++neighbor_count;
-          float ddepth = dp->raw_to_float_depth * dd;
+          float ddepth = raw_to_float_depth * dd;
           bso_f3 other = bso_make3(ddepth * (u.fx_inv * dx + u.cx_inv), ddepth * (u.fy_inv * dy + u.cy_inv), ddepth);
           float dsq = bso_sqlen(bso_sub(other, local));
           if (dsq < min_sq) min_sq = dsq;
@@ -176,7 +215,35 @@ void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_
       BSO_AT(uint16_t, out_depth, y, x) = valid ? d16 : BSLAM_UNKNOWN_DEPTH;
     }
   }
-  free(tmp);
+}
+
+/* ComputeMinMaxDepthCUDA BS/cuda_depth_processing.cu:391-465 (init values inf / 0, BS/cuda_depth_processing.cu:374-388) */
+void bso_compute_min_max_depth(const bslam_buffer2d* depth, float raw_to_float_depth, float* min_depth_out, float* max_depth_out) {
+  float min_depth = INFINITY, max_depth = 0.f;
+  for (int y = 0; y < depth->height; ++y) {
+    for (int x = 0; x < depth->width; ++x) {
+      const uint16_t d16 = BSO_AT(uint16_t, depth, y, x);
+      if (d16 & BSLAM_INVALID_DEPTH_BIT) continue;
+      const float dm = raw_to_float_depth * d16;
+      if (dm < min_depth) min_depth = dm;
+      if (dm > max_depth) max_depth = dm;
+    }
+  }
   if (min_depth_out) *min_depth_out = min_depth;
   if (max_depth_out) *max_depth_out = max_depth;
+}
+
+/* The depth half of the Keyframe constructor from raw images (BS/keyframe.cc:117-147): normals, radii + isolated
+ * pixel removal, min / max of the normals stage's depth. */
+void bso_preprocess_depth(const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+                          const bslam_buffer2d* in_depth, const bslam_buffer2d* out_depth,
+                          const bslam_buffer2d* out_normals, const bslam_buffer2d* out_radius,
+                          float* min_depth_out, float* max_depth_out) {
+  const int w = in_depth->width, h = in_depth->height;
+  uint16_t* tmp = (uint16_t*)malloc((size_t)w * h * sizeof(uint16_t));
+  bslam_buffer2d tmp_buf = {tmp, h, w, (size_t)w * sizeof(uint16_t)};
+  bso_compute_normals(depth_camera, dp, in_depth, &tmp_buf, out_normals);
+  bso_compute_point_radii_and_remove_isolated_pixels(depth_camera, dp->raw_to_float_depth, &tmp_buf, out_radius, out_depth);
+  bso_compute_min_max_depth(&tmp_buf, dp->raw_to_float_depth, min_depth_out, max_depth_out);
+  free(tmp);
 }

@@ -69,6 +69,10 @@ def lib():
         "bso_update_cfactors_from_pcg_delta": (None, [_BUF, C.c_uint32, f32p]),
         "bso_optimize_intrinsics": (None, [C.c_int, C.c_int, C.c_int, _KFS, _CAM, _CAM, _DP, C.c_uint32, _BUF, _CAM, _CAM, f32p, C.c_int]),
         "bso_compute_brightness": (None, [C.c_int, C.c_int, C.c_void_p, _BUF]),
+        "bso_bilateral_filter_and_depth_cutoff": (None, [C.c_float, C.c_float, C.c_float, C.c_uint16, C.c_float, _BUF, _BUF]),
+        "bso_compute_normals": (None, [_CAM, _DP, _BUF, _BUF, _BUF]),
+        "bso_compute_point_radii_and_remove_isolated_pixels": (None, [_CAM, C.c_float, _BUF, _BUF, _BUF]),
+        "bso_compute_min_max_depth": (None, [_BUF, C.c_float, f32p, f32p]),
         "bso_preprocess_depth": (None, [_CAM, _DP, _BUF, _BUF, _BUF, _BUF, f32p, f32p]),
         "bso_create_surfels_for_keyframe": (C.c_uint32, [_CAM, _CAM, _DP, _KFS, P(abi.SE3f), u32p, C.c_uint32, _BUF, C.c_int]),
         "bso_create_surfels_for_keyframe_ex": (C.c_uint32, [C.c_int, C.c_int, _CAM, _CAM, _DP, _KFS, P(abi.Mat3x4), C.c_int, _KFS, P(abi.Mat3x4),

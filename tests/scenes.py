@@ -26,7 +26,7 @@ def unproject_dirs(cam, width, height):
     return np.meshgrid(dx, dy)
 
 
-def pose_geometric_scene(seed=0, width=W, height=H, cell=1, max_surfels=1000 * 1000):
+def pose_geometric_scene(seed=0, width=W, height=H, cell=1, max_surfels=1000 * 1000, return_raw=False):
     """Optimization.PoseOptimizationWithGeometricResidual
     (BS/test/test_pose_optimization_geometric_residual.cc:50-131): one keyframe at identity
     looking at 3 vertical plane strips, depth residuals only."""
@@ -51,6 +51,8 @@ def pose_geometric_scene(seed=0, width=W, height=H, cell=1, max_surfels=1000 * 1
     rgb = np.zeros((height, width, 3), np.uint8)
     kf = scene.add_keyframe_from_images(depth, rgb, bso.se3_identity())
     scene.create_surfels_for_keyframe(kf)
+    if return_raw:
+        return scene, kf, depth, rgb
     return scene, kf
 
 
