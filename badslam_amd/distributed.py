@@ -40,12 +40,17 @@ class AllReduceHook:
         self.device = device
         self.group = group
         self.calls = 0
+        self._views = {}   # (ptr, count) -> torch view of the library's device buffer (the slabs are long-lived)
         self.callback = abi.ALLREDUCE_FN(self._call)
 
     def _call(self, user, ptr, count, stream):
         try:
             if self.device:
-                t = self.torch.as_tensor(_CudaBlob(ptr, count), device="cuda")
+                t = self._views.get((ptr, count))
+                if t is None:
+                    if len(self._views) > 64:
+                        self._views.clear()
+                    t = self._views[(ptr, count)] = self.torch.as_tensor(_CudaBlob(ptr, count), device="cuda")
             else:
                 arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(count,))
                 t = self.torch.from_numpy(arr)

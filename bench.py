@@ -58,11 +58,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # one rank per GPU.  (Rehearsal on a one-GPU box: BSLAM_BENCH_BACKEND=gloo lets several ranks share the card --
+    # RCCL itself needs one GPU per rank.)
+    backend = os.environ.get("BSLAM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     use_desc = bool(args.photometric)
     K = args.keyframes
@@ -75,7 +82,7 @@ def main():
     S = dev.surfels_size
 
     L = badslam_amd.lib()
-    ctx = badslam_amd.Context(local_rank)
+    ctx = badslam_amd.Context(dev_index)
     L.bslam_set_keyframe_cache(ctx.handle, 1)   # the bench never rewrites a keyframe image in place
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     dp = dev.depth_params()
