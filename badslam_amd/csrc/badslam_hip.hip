@@ -693,14 +693,17 @@ int bslam_optimize_geometry_iteration(
   int rc = geometry_common(ctx, stream, color_camera, depth_camera, depth_params, use_descriptor_residuals != 0, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+#ifndef BSLAM_GEOM_R
+#define BSLAM_GEOM_R 3
+#endif
   Schedule sc;
-  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? 1 : BSLAM_GEOM_R, &sc))) return rc;
   const dim3 grid(8u * sc.slots_per_xcd), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
   {
   ProfScope prof(ctx, stream, 1);
-  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_kernel<1, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   }

@@ -273,4 +273,84 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
   }
 }
 
+// kMode 1 with R surfels (granules) per thread, interleaved keyframe by keyframe.  With R = 2 the whole grid
+// (ceil(S / 512) workgroups) is resident at once on 256 CUs for S <= 1M, so all workgroups walk the keyframe
+// table in near lockstep and the XCD's L2 serves the records of the few keyframes in flight (a grid that needs a
+// second round of workgroups runs two phases of the table at once).  Per-surfel sums are still formed in keyframe
+// order: same bits as the R = 1 kernel.
+template <int R>
+__global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  uint32_t idx[R];
+  bool on[R];
+  f3 gp[R], gn[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    idx[r] = surfel_of_slot(sc, slot, r, R);
+    on[r] = idx[r] < s.size;
+    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    const uint32_t j = on[r] ? idx[r] : 0;
+    gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
+    gn[r] = unpack_normal(s.normal[j]);
+  }
+  {
+    float sx[R], sy[R], sz[R], cnt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev& kf = kfs[k];
+      if (kf.activation == BSLAM_KF_INACTIVE) continue;
+      const float* Rm = kf.global_R_frame;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        Proj p;
+        if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        sx[r] += Rm[0] * ln.x + Rm[1] * ln.y + Rm[2] * ln.z;
+        sy[r] += Rm[3] * ln.x + Rm[4] * ln.y + Rm[5] * ln.z;
+        sz[r] += Rm[6] * ln.x + Rm[7] * ln.y + Rm[8] * ln.z;
+        cnt[r] += 1.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (on[r] && cnt[r] >= 1) {
+        const float inv = 1.f / cnt[r];
+        const uint32_t packed = pack_normal(mk3(inv * sx[r], inv * sy[r], inv * sz[r]));
+        s.normal[idx[r]] = packed;
+        gn[r] = unpack_normal(packed);
+      }
+    }
+  }
+  float H[R], b[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
+  for (int k = 0; k < kf_count; ++k) {
+    const KfDev& kf = kfs[k];
+    if (kf.activation == BSLAM_KF_INACTIVE) continue;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Proj p;
+      if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, p.n_local, c.baseline_fx);
+      const float dj = -inv_stddev;
+      const f3 lu = unproject(c, p.px, p.py, p.depth);
+      const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+      const float w = depth_weight(raw);
+      const float wj = w * dj;
+      H[r] += wj * dj;
+      b[r] += wj * raw;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (on[r] && H[r] > 1e-6f) {
+      const float t = -1.f * b[r] / H[r];
+      const f3 np = add3(gp[r], scale3(t, gn[r]));
+      s.x[idx[r]] = np.x; s.y[idx[r]] = np.y; s.z[idx[r]] = np.z;
+    }
+  }
+}
+
 }  // namespace bslam

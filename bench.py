@@ -204,6 +204,20 @@ def geometry_roofline(S, K, frac_inb, frac_assoc, use_desc, launches, total_ms):
             "traffic": pmc_traffic(use_desc, "geometry_kernel")}
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup quota if there is one (a GPU box hands out a share of its
+    cores), else the affinity mask.  Oversubscribing the share only slows the baseline down."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(stack, K, use_desc, budget_s):
     """The oracle (kind "port": this repo's CPU restatement; the reference has no CPU cost
     evaluation) timed on the host cores on a bounded sample: whole pose passes
@@ -225,7 +239,7 @@ def cpu_baseline(stack, K, use_desc, budget_s):
         v.frame_T_global, v.global_R_frame, v.activation, v.id = M, Rg, 0, k
     Hb = np.zeros((K, 27), np.float32)
     counts = np.zeros(K, np.uint32)
-    cores = os.cpu_count() or 1
+    cores = host_cpu_share()
     passes, t0, used = 0, time.perf_counter(), 1
     while True:
         used = L.bso_bench_pose_pass(1, int(use_desc), C.byref(stack.camera), C.byref(stack.camera), C.byref(dp), K, kfs,
