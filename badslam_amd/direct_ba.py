@@ -77,6 +77,95 @@ def se3f_from7(p):
     return T
 
 
+# ---- file formats (badslam_amd/host/io.hpp) -----------------------------------------------------------------
+def _io_lib():
+    L = host_lib()
+    if getattr(L, "_io_ready", False):
+        return L
+    L.bsh_png_info.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    L.bsh_read_png_gray16.argtypes = [C.c_char_p, C.POINTER(C.c_uint16), C.c_size_t]
+    L.bsh_read_png_rgb8.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_size_t]
+    L.bsh_tum_open.restype = C.c_void_p
+    L.bsh_tum_open.argtypes = [C.c_char_p, C.c_char_p]
+    L.bsh_tum_close.argtypes = [C.c_void_p]
+    L.bsh_tum_frame_count.argtypes = [C.c_void_p]
+    L.bsh_tum_camera.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bsh_tum_frame.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bsh_save_poses.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int, C.c_char_p]
+    L.bsh_save_calibration_arrays.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.bsh_load_calibration_arrays.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.bsh_save_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    L.bsh_load_calibration.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    L._io_ready = True
+    return L
+
+
+def _io_check(L, rc):
+    if rc != 0:
+        raise DirectBAError(L.bsh_last_error().decode())
+
+
+def read_png(path):
+    """16-bit gray -> (h, w) uint16; 8-bit colour / gray -> (h, w, 3) uint8."""
+    L = _io_lib()
+    info = (C.c_int * 4)()
+    _io_check(L, L.bsh_png_info(str(path).encode(), info))
+    w, h, depth, channels = info[0], info[1], info[2], info[3]
+    if channels == 1 and depth == 16:
+        out = np.zeros((h, w), np.uint16)
+        _io_check(L, L.bsh_read_png_gray16(str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_uint16)), out.size))
+        return out
+    out = np.zeros((h, w, 3), np.uint8)
+    _io_check(L, L.bsh_read_png_rgb8(str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+    return out
+
+
+def read_tum_dataset(folder, trajectory_filename=None):
+    """ReadTUMRGBDDatasetAssociatedAndCalibrated: dict(width, height, camera (corner convention), frames=[dict])."""
+    L = _io_lib()
+    h = L.bsh_tum_open(str(folder).encode(), trajectory_filename.encode() if trajectory_filename else None)
+    if not h:
+        raise DirectBAError(L.bsh_last_error().decode())
+    try:
+        cam = (C.c_float * 4)()
+        w, ht = C.c_int(), C.c_int()
+        L.bsh_tum_camera(h, cam, C.byref(w), C.byref(ht))
+        frames = []
+        for i in range(L.bsh_tum_frame_count(h)):
+            bufs = [C.create_string_buffer(512) for _ in range(4)]
+            p_rgb, p_depth = np.zeros(7, np.float32), np.zeros(7, np.float32)
+            _io_check(L, L.bsh_tum_frame(h, i, bufs[0], bufs[1], bufs[2], bufs[3], 512, _f(p_rgb), _f(p_depth)))
+            frames.append(dict(rgb_path=bufs[0].value.decode(), depth_path=bufs[1].value.decode(), rgb_timestamp=bufs[2].value.decode(),
+                               depth_timestamp=bufs[3].value.decode(), rgb_global_T_frame=p_rgb, depth_global_T_frame=p_depth))
+        return dict(width=w.value, height=ht.value, camera=np.array(list(cam), np.float32), frames=frames)
+    finally:
+        L.bsh_tum_close(h)
+
+
+def save_poses(timestamp_strings, poses7, start_frame, path):
+    """SavePoses (BS/io.cc:537-568); poses7 = (n, 7) rows qx qy qz qw tx ty tz of global_T_frame."""
+    L = _io_lib()
+    n = len(timestamp_strings)
+    arr = (C.c_char_p * n)(*[t.encode() for t in timestamp_strings])
+    p = np.ascontiguousarray(poses7, np.float32)
+    _io_check(L, L.bsh_save_poses(n, arr, _f(p), start_frame, str(path).encode()))
+
+
+def save_calibration_arrays(base, depth4, color4, a, cfactor):
+    L = _io_lib()
+    cf = np.ascontiguousarray(cfactor, np.float32)
+    _io_check(L, L.bsh_save_calibration_arrays(str(base).encode(), _f(np.ascontiguousarray(depth4, np.float32)), _f(np.ascontiguousarray(color4, np.float32)),
+                                               a, cf.shape[1], cf.shape[0], _f(cf)))
+
+
+def load_calibration_arrays(base, cfactor_shape):
+    L = _io_lib()
+    d, c, a = np.zeros(4, np.float32), np.zeros(4, np.float32), C.c_float()
+    cf = np.zeros(cfactor_shape, np.float32)
+    _io_check(L, L.bsh_load_calibration_arrays(str(base).encode(), _f(d), _f(c), C.byref(a), cf.shape[1], cf.shape[0], _f(cf)))
+    return d, c, a.value, cf
+
+
 class DirectBA:
     """Drives bslam_host::DirectBA.  Constructor arguments are those of BS/direct_ba.h:73-88."""
 
@@ -132,6 +221,14 @@ class DirectBA:
         self._check(self.L.bsh_get_keyframe_images(self._ba, self.stream, kf_id, p16(depth), p16(normals), p16(radius),
                                                    color.ctypes.data_as(C.POINTER(C.c_uint8)), _f(mm)))
         return depth, normals, radius, color, float(mm[0]), float(mm[1])
+
+    def SaveCalibration(self, base_path):
+        L = _io_lib()
+        self._check(L.bsh_save_calibration(self._ba, self.stream, str(base_path).encode()))
+
+    def LoadCalibration(self, base_path):
+        L = _io_lib()
+        self._check(L.bsh_load_calibration(self._ba, self.stream, str(base_path).encode()))
 
     def SetSurfels(self, rows, count):
         rows = np.ascontiguousarray(rows, np.float32)

@@ -6,13 +6,14 @@
 #include <string>
 
 #include "direct_ba.hpp"
+#include "io.hpp"
 
 using namespace bslam_host;
 
 static thread_local std::string g_err;
 
-#define BSH_TRY(body)                         \
-  try { body; return 0; }                     \
+#define BSH_TRY(...)                          \
+  try { __VA_ARGS__; return 0; }              \
   catch (const std::exception& e) { g_err = e.what(); return -1; } \
   catch (...) { g_err = "unknown exception"; return -1; }
 
@@ -186,6 +187,95 @@ int bsh_get_intrinsics(void* ba_, float* color4, float* depth4, float* a) {
     std::memcpy(color4, ba->color_camera().parameters(), 16);
     std::memcpy(depth4, ba->depth_camera().parameters(), 16);
     *a = ba->a();
+  });
+}
+
+// ---- file formats (io.hpp) ----
+int bsh_png_info(const char* path, int* whbc /* width, height, bit depth, channels */) {
+  PngInfo info;
+  if (!ReadPngInfo(path, &info)) { g_err = std::string("cannot read PNG header of ") + path; return -1; }
+  whbc[0] = info.width; whbc[1] = info.height; whbc[2] = info.bit_depth; whbc[3] = info.channels;
+  return 0;
+}
+int bsh_read_png_gray16(const char* path, uint16_t* out, size_t capacity) {
+  int w, h;
+  std::vector<uint16_t> img;
+  if (!ReadPngGray16(path, &w, &h, &img) || img.size() > capacity) { g_err = std::string("cannot read 16-bit PNG ") + path; return -1; }
+  std::memcpy(out, img.data(), img.size() * sizeof(uint16_t));
+  return 0;
+}
+int bsh_read_png_rgb8(const char* path, uint8_t* out, size_t capacity) {
+  int w, h;
+  std::vector<uint8_t> img;
+  if (!ReadPngRgb8(path, &w, &h, &img) || img.size() > capacity) { g_err = std::string("cannot read 8-bit PNG ") + path; return -1; }
+  std::memcpy(out, img.data(), img.size());
+  return 0;
+}
+void* bsh_tum_open(const char* folder, const char* trajectory_filename) {
+  auto ds = std::make_unique<TumDataset>();
+  if (!ReadTUMRGBDDatasetAssociatedAndCalibrated(folder, trajectory_filename ? trajectory_filename : "", ds.get())) {
+    g_err = std::string("cannot read TUM RGB-D dataset ") + folder;
+    return nullptr;
+  }
+  return ds.release();
+}
+void bsh_tum_close(void* ds) { delete static_cast<TumDataset*>(ds); }
+int bsh_tum_frame_count(void* ds) { return static_cast<int>(static_cast<TumDataset*>(ds)->frames.size()); }
+int bsh_tum_camera(void* ds_, float* params4, int* width, int* height) {
+  const TumDataset* ds = static_cast<TumDataset*>(ds_);
+  std::memcpy(params4, ds->camera_parameters, 16);
+  *width = ds->width; *height = ds->height;
+  return 0;
+}
+int bsh_tum_frame(void* ds_, int i, char* rgb_path, char* depth_path, char* rgb_ts, char* depth_ts, size_t capacity, float* rgb_pose7, float* depth_pose7) {
+  const TumDataset* ds = static_cast<TumDataset*>(ds_);
+  if (i < 0 || i >= static_cast<int>(ds->frames.size())) { g_err = "frame index out of range"; return -1; }
+  const TumFrame& f = ds->frames[static_cast<size_t>(i)];
+  std::snprintf(rgb_path, capacity, "%s", f.rgb_path.c_str());
+  std::snprintf(depth_path, capacity, "%s", f.depth_path.c_str());
+  std::snprintf(rgb_ts, capacity, "%s", f.rgb_timestamp_string.c_str());
+  std::snprintf(depth_ts, capacity, "%s", f.depth_timestamp_string.c_str());
+  pose_to7(f.rgb_global_T_frame, rgb_pose7);
+  pose_to7(f.depth_global_T_frame, depth_pose7);
+  return 0;
+}
+int bsh_save_poses(int count, const char* const* timestamp_strings, const float* poses7, int start_frame, const char* path) {
+  std::vector<std::string> ts(static_cast<size_t>(count));
+  std::vector<SE3f> poses(static_cast<size_t>(count));
+  for (int i = 0; i < count; ++i) { ts[i] = timestamp_strings[i]; poses[i] = pose_from7(poses7 + 7 * i); }
+  if (!SavePoses(ts, poses, start_frame, path)) { g_err = std::string("cannot write ") + path; return -1; }
+  return 0;
+}
+int bsh_save_calibration_arrays(const char* base, const float* depth4, const float* color4, float a, int w, int h, const float* cfactor) {
+  if (!SaveCalibration(base, depth4, color4, a, w, h, cfactor)) { g_err = std::string("cannot write calibration ") + base; return -1; }
+  return 0;
+}
+int bsh_load_calibration_arrays(const char* base, float* depth4, float* color4, float* a, int w, int h, float* cfactor) {
+  if (!LoadCalibration(base, depth4, color4, a, w, h, cfactor)) { g_err = std::string("cannot read calibration ") + base; return -1; }
+  return 0;
+}
+// SaveCalibration / LoadCalibration of BS/io.cc:570-700 on a DirectBA
+int bsh_save_calibration(void* ba_, void* stream, const char* base) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    const int w = ba->cfactor_buffer().width(), h = ba->cfactor_buffer().height();
+    std::vector<float> cf(static_cast<size_t>(w) * h);
+    ba->cfactor_buffer().Download(static_cast<hipStream_t>(stream), cf.data(), static_cast<size_t>(w) * sizeof(float));
+    if (!SaveCalibration(base, ba->depth_camera().parameters(), ba->color_camera().parameters(), ba->a(), w, h, cf.data()))
+      throw std::runtime_error(std::string("cannot write calibration ") + base);
+  });
+}
+int bsh_load_calibration(void* ba_, void* stream, const char* base) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    const int w = ba->cfactor_buffer().width(), h = ba->cfactor_buffer().height();
+    std::vector<float> cf(static_cast<size_t>(w) * h);
+    float d[4], c[4], a = 0.f;
+    if (!LoadCalibration(base, d, c, &a, w, h, cf.data())) throw std::runtime_error(std::string("cannot read calibration ") + base);
+    ba->SetDepthCamera(PinholeCamera4f(ba->depth_camera().width(), ba->depth_camera().height(), d));
+    ba->SetColorCamera(PinholeCamera4f(ba->color_camera().width(), ba->color_camera().height(), c));
+    ba->SetA(a);
+    ba->UploadCFactor(static_cast<hipStream_t>(stream), cf.data());
   });
 }
 

@@ -216,6 +216,11 @@ class DirectBA {
   void SetDepthCamera(const PinholeCamera4f& camera) { depth_camera_ = camera; }   // BS/direct_ba.h (used by the intrinsics tests)
   void SetColorCamera(const PinholeCamera4f& camera) { color_camera_ = camera; }
   const DeviceBuffer<float>& cfactor_buffer() const { return *cfactor_buffer_; }
+  // host row-major cfactor image -> device (LoadCalibration, BS/io.cc:694); invalidates the derived records
+  void UploadCFactor(hipStream_t stream, const float* host) {
+    cfactor_buffer_->Upload(stream, host, static_cast<size_t>(cfactor_buffer_->width()) * sizeof(float));
+    InvalidateKeyframeCache();
+  }
   u32 surfels_size() const { return surfels_size_; }
   u32 surfel_count() const { return surfel_count_; }
   const DeviceBuffer<float>& surfels() const { return *surfels_; }

@@ -288,3 +288,18 @@ def test_intrinsics_optimization_with_photometric_residual(oracle, use_pcg):
     cc, _, _ = ba.intrinsics()
     err = np.abs(cc - np.array([true.fx, true.fy, true.cx, true.cy], np.float32))
     assert err[0] < 0.03 and err[1] < 0.03 and err[2] < 0.15 and err[3] < 0.15, err
+
+
+def test_save_and_load_calibration_through_direct_ba(oracle, tmp_path):
+    """SaveCalibration / LoadCalibration (BS/io.cc:570-700) on the host class: intrinsics, a and the device cfactor image."""
+    scene = scenes.synthetic_scene(2, seed=3, cell=4)
+    ba = make_ba(scene)
+    d = scene.depth_camera
+    ba.set_intrinsics([d.fx + 1.5, d.fy - 2.5, d.cx + 0.25, d.cy - 0.75], [d.fx - 0.5, d.fy + 0.5, d.cx + 1.0, d.cy + 2.0], 0.0175)
+    ba.SaveCalibration(tmp_path / "c")
+    other = make_ba(scene)
+    other.LoadCalibration(tmp_path / "c")
+    c1, d1, a1 = ba.intrinsics()
+    c2, d2, a2 = other.intrinsics()
+    assert np.allclose(c1, c2, atol=2e-3) and np.allclose(d1, d2, atol=2e-3) and abs(a1 - a2) < 1e-7   # 6 significant digits in the files
+    assert np.array_equal(other.cfactor(scene.cfactor.shape), ba.cfactor(scene.cfactor.shape))
