@@ -1,0 +1,88 @@
+"""-m gpu: the rows either side of the path working together.  A synthetic TUM RGB-D directory (PNG depth / colour,
+associated.txt, calibration.txt, ground-truth trajectory) is read back with the host reader, every frame becomes a
+keyframe through the device preprocessing (raw-image Keyframe constructor), and BundleAdjustment with
+do_surfel_updates creates, merges, deletes and compacts the surfels while it refines perturbed keyframe poses.
+The recovered poses must be much closer to the ground truth than the perturbed start, and the exported pose file
+must read back."""
+import numpy as np
+import pytest
+
+from badslam_amd import direct_ba as dba
+from tests import bso, scenes
+from tests.test_io_cpu import write_png
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tum_directory_to_bundle_adjusted_poses(oracle, tmp_path):
+    W, H, K = 320, 240, 6
+    rng = np.random.default_rng(42)
+    cam = bso.make_camera(262.5, 262.5, 160.0, 120.0, W, H)
+    raw_to_float = np.float32(1.0 / 5000)
+    planes = scenes.random_planes(rng, 20)
+    (tmp_path / "rgb").mkdir()
+    (tmp_path / "depth").mkdir()
+    assoc, traj, gt = [], ["# timestamp tx ty tz qx qy qz qw"], []
+    for k in range(K):
+        xi = np.concatenate([rng.uniform(-0.15, 0.15, 3), rng.uniform(-0.08, 0.08, 3)]).astype(np.float32)
+        T = bso.se3_exp(xi if k else np.zeros(6, np.float32))
+        M = np.array(list(bso.se3_matrix3x4(T).m), np.float64).reshape(3, 4)
+        tt, pidx, dg, o = scenes.render_planes(cam, W, H, M[:, :3], M[:, 3], planes)
+        valid = np.isfinite(tt) & (tt < 6.0)
+        depth = np.where(valid, tt / float(raw_to_float) + 0.5, 0).astype(np.uint32)
+        depth = np.where(depth >= 32768, 0, depth).astype(np.uint16)       # 0 = no measurement, as in the TUM PNGs
+        pts = o[None, None, :] + dg * np.where(valid, tt, 0.0)[..., None]
+        lum = scenes.texture_at(pts, pidx, 0.37)
+        ts = f"{100.0 + 0.5 * k:.6f}"
+        write_png(tmp_path / "rgb" / f"{ts}.png", np.repeat(lum[:, :, None], 3, axis=2), filter_type=k % 5)
+        write_png(tmp_path / "depth" / f"{ts}.png", depth, filter_type=(k + 2) % 5)
+        assoc.append(f"{ts} rgb/{ts}.png {ts} depth/{ts}.png")
+        q = bso.se3_to_np(T)
+        traj.append(f"{ts} {q[4]:.9g} {q[5]:.9g} {q[6]:.9g} {q[0]:.9g} {q[1]:.9g} {q[2]:.9g} {q[3]:.9g}")
+        gt.append(T)
+    (tmp_path / "associated.txt").write_text("\n".join(assoc) + "\n")
+    (tmp_path / "calibration.txt").write_text(f"{cam.fx} {cam.fy} {cam.cx - 0.5} {cam.cy - 0.5}\n")   # pixel-centre convention on disk
+    (tmp_path / "groundtruth.txt").write_text("\n".join(traj) + "\n")
+
+    ds = dba.read_tum_dataset(tmp_path, "groundtruth.txt")
+    assert (ds["width"], ds["height"], len(ds["frames"])) == (W, H, K)
+    assert np.allclose(ds["camera"], [cam.fx, cam.fy, cam.cx, cam.cy])
+    read_cam = bso.make_camera(*[float(v) for v in ds["camera"]], W, H)
+
+    ba = dba.DirectBA(200000, float(raw_to_float), 40.0, 4, 0.8, 1, 2, 2, read_cam, read_cam, 0, True, True)
+    ba.set_options(pcg_gauge_keyframe=0)
+    start = []
+    for k, fr in enumerate(ds["frames"]):
+        depth = dba.read_png(fr["depth_path"])
+        depth = np.where(depth == 0, 65535, depth).astype(np.uint16)      # the bilateral filter stage maps 0 to "unknown" (BS/cuda_depth_processing.cu:57-60)
+        rgb = dba.read_png(fr["rgb_path"])
+        T_gt = dba.se3f_from7(fr["depth_global_T_frame"])
+        noise = np.concatenate([rng.choice([-1, 1], 3) * 0.004, rng.choice([-1, 1], 3) * 0.002]).astype(np.float32)
+        T0 = bso.se3_mul(T_gt, bso.se3_exp(noise if k else np.zeros(6, np.float32)))
+        start.append(T0)
+        assert ba.AddKeyframeFromImages(k, depth, rgb, T0) == k
+
+    def pose_errors(poses):
+        # relative to keyframe 0 (the gauge freedom of BA)
+        out = []
+        for k in range(1, K):
+            rel = bso.se3_mul(bso.se3_inverse(poses[0]), poses[k])
+            rel_gt = bso.se3_mul(bso.se3_inverse(gt[0]), gt[k])
+            out.append(np.abs(bso.se3_log(bso.se3_mul(bso.se3_inverse(rel), rel_gt))).max())
+        return np.array(out)
+
+    before = pose_errors(start)
+    for _ in range(3):
+        ba.BundleAdjustment(False, False, True, True, True, 5, 30, False, 0, K - 1, True)
+    n = ba.surfels_size()
+    assert 3000 < n < 30000, n      # 80 x 60 cells per keyframe, overlapping views, >= 2 observations each
+    assert not np.isnan(ba.GetSurfels(8)[0]).any()
+    after = pose_errors([ba.keyframe_pose(k) for k in range(K)])
+    assert before.min() > 1.5e-3
+    assert after.max() < 3e-4 and after.max() < 0.1 * before.max(), (before, after)
+
+    # pose export (BS/io.cc:537-568) reads back as a TUM trajectory
+    poses7 = np.array([dba.pose7(ba.keyframe_pose(k)) for k in range(K)], np.float32)
+    dba.save_poses([f["depth_timestamp"] for f in ds["frames"]], poses7, 0, tmp_path / "poses.txt")
+    back = (tmp_path / "poses.txt").read_text().splitlines()
+    assert len(back) == K + 1 and back[1].split()[0] == ds["frames"][0]["depth_timestamp"]
