@@ -103,6 +103,18 @@ SIGNATURES = {
     "bslam_compute_point_radii_and_remove_isolated_pixels": (C.c_int, [C.c_void_p, C.c_void_p, P(Camera4f), C.c_float, P(Buffer2D), P(Buffer2D),
                                                                       P(Buffer2D)]),
     "bslam_compute_min_max_depth": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), C.c_float, P(C.c_float), P(C.c_float)]),
+    "bslam_compute_brightness_from_color": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), P(Buffer2D)]),
+    "bslam_set_to_read_mode_normalized": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), P(Buffer2D)]),
+    "bslam_calibrate_depth": (C.c_int, [C.c_void_p, C.c_void_p, P(DepthParams), P(Buffer2D), P(Buffer2D)]),
+    "bslam_calibrate_depth_and_transform_color_to_depth": (C.c_int, [C.c_void_p, C.c_void_p, P(Camera4f), P(Camera4f), P(DepthParams), P(Buffer2D),
+                                                                    P(Buffer2D), P(Buffer2D), P(Buffer2D)]),
+    "bslam_downsample_images": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Buffer2D)]),
+    "bslam_accumulate_pose_coeffs_from_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), C.c_float, C.c_float,
+                                                          P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Mat3x4), P(Buffer2D), P(Buffer2D), P(Buffer2D),
+                                                          P(C.c_uint32), P(C.c_float), P(C.c_float)]),
+    "bslam_compute_cost_and_residual_count_from_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), C.c_float,
+                                                                   C.c_float, P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Mat3x4), P(Buffer2D),
+                                                                   P(Buffer2D), P(Buffer2D), P(C.c_uint32), P(C.c_float)]),
     "bslam_compact_surfels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32), P(Buffer2D), P(Buffer2D)]),
     "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -13,6 +13,7 @@
 #include "pcg_kernels.hpp"
 #include "lifecycle_kernels.hpp"
 #include "preprocess_kernels.hpp"
+#include "odometry_kernels.hpp"
 #include "pose_kernels.hpp"
 
 namespace bslam {
@@ -352,7 +353,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->order.release(); ctx->intr_cells.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->intr_cells.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
@@ -762,3 +763,4 @@ int bslam_debug_pose_residuals(
 #include "pcg_abi.inc"
 #include "lifecycle_abi.inc"
 #include "preprocess_abi.inc"
+#include "odometry_abi.inc"

@@ -222,6 +222,19 @@ class DirectBA:
                                                    color.ctypes.data_as(C.POINTER(C.c_uint8)), _f(mm)))
         return depth, normals, radius, color, float(mm[0]), float(mm[1])
 
+    def TrackKeyframePair(self, tracked_id, base_id, init1, init2=None, num_scales=5, test_different_initial_estimates=False):
+        """TrackFramePairwise (BS/pairwise_frame_tracking.cc:256-678) of keyframe `tracked_id` against keyframe `base_id`:
+        returns (base_T_tracked, iterations per scale)."""
+        self.L.bsh_track_keyframe_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                   C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        out = np.zeros(7, np.float32)
+        its = (C.c_int * num_scales)()
+        p1 = pose7(init1)
+        p2 = pose7(init2 if init2 is not None else init1)
+        self._check(self.L.bsh_track_keyframe_pair(self._ba, self.stream, tracked_id, base_id, num_scales, int(test_different_initial_estimates), _f(p1), _f(p2),
+                                                   _f(out), its))
+        return se3f_from7(out), list(its)
+
     def SaveCalibration(self, base_path):
         L = _io_lib()
         self._check(L.bsh_save_calibration(self._ba, self.stream, str(base_path).encode()))

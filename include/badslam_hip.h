@@ -410,6 +410,54 @@ int bslam_compute_min_max_depth(
     bslam_context* ctx, void* stream, const bslam_buffer2d* depth_buffer, float raw_to_float_depth,
     float* min_depth, float* max_depth);
 
+/* ------------------------------------------------------------------------- */
+/* Pairwise frame tracking / odometry                        */
+/* ------------------------------------------------------------------------- */
+/* The image-pair variants of the pose kernels and the pyramid construction used by TrackFramePairwise
+ * (BS/pairwise_frame_tracking.cc:256-678; the coarse-to-fine loop itself is host code, see
+ * badslam_amd/host/pairwise_frame_tracking.hpp).  Depth pyramids are f32 (0 = invalid), colour pyramids u8
+ * single channel ("textures" of the reference are plain u8 images here), normals u16.  GradientXY variant
+ * (use_gradmag = false, BS/bad_slam.cc:831). */
+
+/* Replaces ComputeBrightnessCUDA(texture overload) (BS/cuda_image_processing.cu:196-222): luma of a uchar4 image. */
+int bslam_compute_brightness_from_color(bslam_context* ctx, void* stream,
+                                        const bslam_buffer2d* color_buffer, const bslam_buffer2d* intensity_buffer);
+/* Replaces CUDABuffer_<u8>::SetToReadModeNormalized (LV/cuda/cuda_buffer.cu:82-102). */
+int bslam_set_to_read_mode_normalized(bslam_context* ctx, void* stream,
+                                      const bslam_buffer2d* input_u8, const bslam_buffer2d* output_u8);
+/* Replaces CalibrateDepthCUDA (BS/kernel_downsample.cu:292-330). */
+int bslam_calibrate_depth(bslam_context* ctx, void* stream, const bslam_depth_params* depth_params,
+                          const bslam_buffer2d* depth_buffer, const bslam_buffer2d* out_depth);
+/* Replaces CalibrateDepthAndTransformColorToDepthCUDA (BS/kernel_downsample.cu:236-290). */
+int bslam_calibrate_depth_and_transform_color_to_depth(
+    bslam_context* ctx, void* stream, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params, const bslam_buffer2d* depth_buffer, const bslam_buffer2d* color_u8,
+    const bslam_buffer2d* out_depth, const bslam_buffer2d* out_color);
+/* Replaces DownsampleImagesCUDA (BS/kernel_downsample.cu:105-234). */
+int bslam_downsample_images(
+    bslam_context* ctx, void* stream, const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer,
+    const bslam_buffer2d* color_u8, const bslam_buffer2d* downsampled_depth,
+    const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color);
+/* Replaces AccumulatePoseEstimationCoeffsFromImagesCUDA (BS/kernels.h:181-203, BS/kernel_opt_pose.cc:99-192): the
+ * "downsampled" images are the tracked frame's pyramid level (colour in the colour camera's intrinsics), the
+ * "surfel" images the base frame's (colour in the depth camera's intrinsics).  Cameras are the level's (scaled).
+ * H (21, upper triangle row-major) and b (6) are valid on return; visible_count may be NULL. */
+int bslam_accumulate_pose_coeffs_from_images(
+    bslam_context* ctx, void* stream, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* downsampled_depth, const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color,
+    uint32_t* visible_count, float* H, float* b);
+/* Replaces ComputeCostAndResidualCountFromImagesCUDA (BS/kernels.h:205-224, BS/kernel_opt_pose.cc:194-270). */
+int bslam_compute_cost_and_residual_count_from_images(
+    bslam_context* ctx, void* stream, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* downsampled_depth, const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color,
+    uint32_t* residual_count, float* residual_sum);
+
 /* Multi-GPU (surfel-sharded) runs of the PCG and intrinsics entry points: every rank holds its own
  * surfel shard and the full keyframe list; `allreduce` sums a device buffer of floats in place across
  * ranks (ordered after prior work on `stream`, e.g. RCCL ncclAllReduce on that stream).  It is

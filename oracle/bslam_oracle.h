@@ -205,6 +205,38 @@ void bso_delete_surfels_and_update_radii(
 void bso_compact_surfels(uint32_t surfel_count, uint32_t* surfels_size, const bslam_buffer2d* surfels,
                          const bslam_buffer2d* active_surfels);
 
+/* ---- pairwise frame tracking / odometry, see bso_odometry.c ------------------ */
+void bso_brightness_from_color(const bslam_buffer2d* color_uchar4, const bslam_buffer2d* out_u8);
+void bso_calibrate_depth(const bslam_depth_params* dp, const bslam_buffer2d* depth_u16, const bslam_buffer2d* out_depth);
+void bso_downsample_images(const bslam_buffer2d* depth, const bslam_buffer2d* normals, const bslam_buffer2d* color_u8, int tex_mode,
+                           const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals, const bslam_buffer2d* out_color);
+/* out: [num_scales][6] images {base depth f32, base normals u16, base colour u8, tracked depth, normals, colour};
+ * free with bso_free_tracking_pyramids */
+void bso_build_tracking_pyramids(
+    int num_scales, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    const bslam_buffer2d* tracked_depth_u16, const bslam_buffer2d* tracked_normals, const bslam_buffer2d* tracked_color_uchar4,
+    const bslam_buffer2d* base_depth_u16, const bslam_buffer2d* base_normals, const bslam_buffer2d* base_color_uchar4, int tex_mode,
+    bslam_buffer2d* out);
+void bso_free_tracking_pyramids(int num_scales, bslam_buffer2d* pyramids);
+void bso_accumulate_pose_coeffs_from_images(
+    int use_depth, int use_desc, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* frame_depth, const bslam_buffer2d* frame_normals, const bslam_buffer2d* frame_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color, int tex_mode,
+    double* H, double* b, uint32_t* visible_count);
+void bso_compute_cost_and_residual_count_from_images(
+    int use_depth, int use_desc, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* frame_depth, const bslam_buffer2d* frame_normals, const bslam_buffer2d* frame_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color, int tex_mode,
+    uint32_t* residual_count, double* cost);
+int bso_is_scale_n_pose_estimation_converged(const float x[6], float scaling_factor);
+void bso_track_frame_pairwise(
+    int num_scales, int use_depth, int use_desc, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    const bslam_buffer2d* tracked_depth_u16, const bslam_buffer2d* tracked_normals, const bslam_buffer2d* tracked_color_uchar4,
+    const bslam_buffer2d* base_depth_u16, const bslam_buffer2d* base_normals, const bslam_buffer2d* base_color_uchar4, int tex_mode,
+    int test_different_initial_estimates, const bslam_se3f* init1, const bslam_se3f* init2, bslam_se3f* out_base_T_frame, int* iterations_per_scale);
+
 #ifdef __cplusplus
 }
 #endif

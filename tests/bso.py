@@ -80,6 +80,14 @@ def lib():
         "bso_determine_supporting_surfels": (None, [C.c_int, C.c_float, _CAM, _DP, _KFS, C.c_uint32, _BUF, u32p, u32p, u32p, u32p]),
         "bso_delete_surfels_and_update_radii": (None, [C.c_int, _CAM, _DP, C.c_int, _KFS, u32p, C.c_uint32, _BUF]),
         "bso_compact_surfels": (None, [C.c_uint32, u32p, _BUF, _BUF]),
+        "bso_track_frame_pairwise": (None, [C.c_int, C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, _BUF, _BUF, _BUF, C.c_int, C.c_int,
+                                            P(abi.SE3f), P(abi.SE3f), P(abi.SE3f), P(C.c_int)]),
+        "bso_build_tracking_pyramids": (None, [C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, _BUF, _BUF, _BUF, C.c_int, _BUF]),
+        "bso_free_tracking_pyramids": (None, [C.c_int, _BUF]),
+        "bso_accumulate_pose_coeffs_from_images": (None, [C.c_int, C.c_int, _CAM, _CAM, C.c_float, C.c_float, _BUF, _BUF, _BUF, P(abi.Mat3x4), _BUF, _BUF,
+                                                          _BUF, C.c_int, f64p, f64p, u32p]),
+        "bso_compute_cost_and_residual_count_from_images": (None, [C.c_int, C.c_int, _CAM, _CAM, C.c_float, C.c_float, _BUF, _BUF, _BUF, P(abi.Mat3x4),
+                                                                   _BUF, _BUF, _BUF, C.c_int, u32p, f64p]),
         "bso_bench_pose_pass": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, C.c_int, f32p, u32p, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -258,6 +266,20 @@ class HostScene:
         self.active[0, self.surfels_size:size.value] = abi.BSLAM_SURFEL_ACTIVE_FLAG
         self.surfels_size = size.value
         return n
+
+    # --- pairwise frame tracking (oracle)
+    def track_frame_pairwise(self, tracked, base, init1, init2=None, num_scales=5, test_different_initial_estimates=False):
+        """TrackFramePairwise (BS/pairwise_frame_tracking.cc:256-678): base_T_frame of `tracked` relative to `base`."""
+        dp = self.depth_params()
+        tv, bv = tracked.view(), base.view()
+        out = abi.SE3f()
+        its = (C.c_int * num_scales)()
+        i2 = init1 if init2 is None else init2
+        lib().bso_track_frame_pairwise(num_scales, int(self.use_depth_residuals), int(self.use_descriptor_residuals), C.byref(self.color_camera),
+                                       C.byref(self.depth_camera), C.byref(dp), C.byref(tv.depth), C.byref(tv.normals), C.byref(tv.color),
+                                       C.byref(bv.depth), C.byref(bv.normals), C.byref(bv.color), self.tex_mode, int(test_different_initial_estimates),
+                                       C.byref(init1), C.byref(i2), C.byref(out), its)
+        return out, list(its)
 
     # --- surfel lifecycle (oracle)
     def covis_args(self, kf, covis):
