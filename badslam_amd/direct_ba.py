@@ -166,6 +166,26 @@ def load_calibration_arrays(base, cfactor_shape):
     return d, c, a.value, cf
 
 
+def state_file_round_trip(src, dst):
+    """LoadState + SaveState of a version-1 state file; returns the summary (ints[8], floats[11])."""
+    L = _io_lib()
+    L.bsh_state_load.restype = C.c_void_p
+    L.bsh_state_load.argtypes = [C.c_char_p]
+    L.bsh_state_free.argtypes = [C.c_void_p]
+    L.bsh_state_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.bsh_state_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+    h = L.bsh_state_load(str(src).encode())
+    if not h:
+        raise DirectBAError(L.bsh_last_error().decode())
+    try:
+        ints, floats = np.zeros(8, np.int32), np.zeros(11, np.float32)
+        L.bsh_state_summary(h, ints.ctypes.data_as(C.POINTER(C.c_int32)), _f(floats))
+        _io_check(L, L.bsh_state_save(h, str(dst).encode()))
+        return ints, floats
+    finally:
+        L.bsh_state_free(h)
+
+
 class DirectBA:
     """Drives bslam_host::DirectBA.  Constructor arguments are those of BS/direct_ba.h:73-88."""
 
@@ -234,6 +254,17 @@ class DirectBA:
         self._check(self.L.bsh_track_keyframe_pair(self._ba, self.stream, tracked_id, base_id, num_scales, int(test_different_initial_estimates), _f(p1), _f(p2),
                                                    _f(out), its))
         return se3f_from7(out), list(its)
+
+    def SaveState(self, path, frame_count):
+        """The DirectBA part of SaveState (BS/io.cc:38-178) as a version-1 state file."""
+        L = _io_lib()
+        L.bsh_state_save_from_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        self._check(L.bsh_state_save_from_ba(self._ba, self.stream, frame_count, str(path).encode()))
+
+    def LoadState(self, path):
+        L = _io_lib()
+        L.bsh_state_load_into_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        self._check(L.bsh_state_load_into_ba(self._ba, self.stream, str(path).encode()))
 
     def SaveCalibration(self, base_path):
         L = _io_lib()

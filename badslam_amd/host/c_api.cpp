@@ -280,6 +280,106 @@ int bsh_load_calibration(void* ba_, void* stream, const char* base) {
   });
 }
 
+// ---- state file v1 ----
+void* bsh_state_load(const char* path) {
+  auto st = std::make_unique<StateV1>();
+  std::string err;
+  if (!LoadState(path, st.get(), &err)) { g_err = err; return nullptr; }
+  return st.release();
+}
+void bsh_state_free(void* st) { delete static_cast<StateV1*>(st); }
+int bsh_state_save(void* st, const char* path) {
+  if (!SaveState(*static_cast<StateV1*>(st), path)) { g_err = std::string("cannot write ") + path; return -1; }
+  return 0;
+}
+// ints: base_kf_id, last_frame_index, frame count, keyframe count, surfel_count, surfels_size, ba_iteration_count, cell size;
+// floats: a, raw_to_float_depth, baseline_fx, depth camera (4), colour camera (4)
+int bsh_state_summary(void* st_, int32_t* ints8, float* floats11) {
+  const StateV1* st = static_cast<StateV1*>(st_);
+  ints8[0] = st->base_kf_id; ints8[1] = st->last_frame_index; ints8[2] = static_cast<int32_t>(st->frame_global_T_frame.size());
+  ints8[3] = static_cast<int32_t>(st->keyframes.size()); ints8[4] = st->surfel_count; ints8[5] = st->surfels_size; ints8[6] = st->ba_iteration_count;
+  ints8[7] = st->sparse_surfel_cell_size;
+  floats11[0] = st->a; floats11[1] = st->raw_to_float_depth; floats11[2] = st->baseline_fx;
+  std::memcpy(floats11 + 3, st->depth_camera_parameters, 16);
+  std::memcpy(floats11 + 7, st->color_camera_parameters, 16);
+  return 0;
+}
+// The DirectBA part of SaveState (BS/io.cc:106-178): cameras, deformation, keyframe metadata, surfels, BA counters.  The SLAM
+// front-end fields (config, motion model, queue) keep their defaults; frame poses = the keyframes' poses at their frame indices.
+int bsh_state_save_from_ba(void* ba_, void* stream_, int frame_count, const char* path) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StateV1 st;
+    st.frame_global_T_frame.assign(static_cast<size_t>(frame_count), SE3f());
+    st.config.raw_to_float_depth = ba->depth_params().raw_to_float_depth;
+    st.config.baseline_fx = ba->depth_params().baseline_fx;
+    st.config.sparse_surfel_cell_size = ba->depth_params().sparse_surfel_cell_size;
+    st.config.use_geometric_residuals = ba->use_depth_residuals();
+    st.config.use_photometric_residuals = ba->use_descriptor_residuals();
+    st.color_camera_width = ba->color_camera().width(); st.color_camera_height = ba->color_camera().height();
+    st.depth_camera_width = ba->depth_camera().width(); st.depth_camera_height = ba->depth_camera().height();
+    std::memcpy(st.color_camera_parameters, ba->color_camera().parameters(), 16);
+    std::memcpy(st.depth_camera_parameters, ba->depth_camera().parameters(), 16);
+    st.cfactor_width = ba->cfactor_buffer().width(); st.cfactor_height = ba->cfactor_buffer().height();
+    st.cfactor.resize(static_cast<size_t>(st.cfactor_width) * st.cfactor_height);
+    ba->cfactor_buffer().Download(stream, st.cfactor.data(), static_cast<size_t>(st.cfactor_width) * sizeof(float));
+    const bslam_depth_params dp = ba->depth_params();
+    st.a = dp.a; st.raw_to_float_depth = dp.raw_to_float_depth; st.baseline_fx = dp.baseline_fx; st.sparse_surfel_cell_size = dp.sparse_surfel_cell_size;
+    for (const auto& kf : ba->keyframes()) {
+      StateKeyframeV1 k;
+      if (kf) {
+        k.id = kf->id(); k.frame_index = static_cast<int32_t>(kf->frame_index()); k.activation = static_cast<int32_t>(kf->activation());
+        k.last_active_in_ba_iteration = kf->last_active_in_ba_iteration(); k.last_covis_in_ba_iteration = kf->last_covis_in_ba_iteration();
+        if (k.frame_index < 0 || k.frame_index >= frame_count) throw std::invalid_argument("keyframe frame index outside the frame list");
+        st.frame_global_T_frame[static_cast<size_t>(k.frame_index)] = kf->global_T_frame();
+      }
+      st.keyframes.push_back(k);
+    }
+    st.surfel_count = static_cast<int32_t>(ba->surfel_count()); st.surfels_size = static_cast<int32_t>(ba->surfels_size());
+    st.surfels.resize(static_cast<size_t>(8) * st.surfels_size);
+    if (st.surfels_size) ba->GetSurfels(stream, st.surfels.data(), static_cast<size_t>(st.surfels_size) * sizeof(float), 8);
+    st.ba_iteration_count = ba->ba_iteration_count(); st.last_ba_iteration_count = ba->last_ba_iteration_count();
+    st.use_depth_residuals = ba->use_depth_residuals(); st.use_descriptor_residuals = ba->use_descriptor_residuals();
+    st.min_observation_count_while_bootstrapping_1 = ba->min_observation_count_while_bootstrapping_1();
+    st.min_observation_count_while_bootstrapping_2 = ba->min_observation_count_while_bootstrapping_2();
+    st.min_observation_count = ba->min_observation_count();
+    st.surfel_merge_dist_factor = ba->surfel_merge_dist_factor();
+    if (!SaveState(st, path)) throw std::runtime_error(std::string("cannot write ") + path);
+  });
+}
+// The DirectBA part of LoadState (BS/io.cc:300-372, 446-475): the keyframes must already exist (the reference re-creates them
+// from the dataset images); their poses come from the per-frame pose list.
+int bsh_state_load_into_ba(void* ba_, void* stream_, const char* path) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StateV1 st;
+    std::string err;
+    if (!LoadState(path, &st, &err)) throw std::runtime_error(err);
+    if (st.cfactor_width != ba->cfactor_buffer().width() || st.cfactor_height != ba->cfactor_buffer().height())
+      throw std::runtime_error("cfactor buffer size mismatch");                      // BS/io.cc:331-335
+    if (st.keyframes.size() != ba->keyframes().size()) throw std::runtime_error("keyframe count mismatch");
+    if (static_cast<u32>(st.surfels_size) > static_cast<u32>(ba->max_surfel_count())) throw std::runtime_error("surfel count exceeds max_surfel_count");   // :452-455
+    ba->SetColorCamera(PinholeCamera4f(st.color_camera_width, st.color_camera_height, st.color_camera_parameters));
+    ba->SetDepthCamera(PinholeCamera4f(st.depth_camera_width, st.depth_camera_height, st.depth_camera_parameters));
+    ba->SetA(st.a);
+    ba->UploadCFactor(stream, st.cfactor.data());
+    for (size_t i = 0; i < st.keyframes.size(); ++i) {
+      const StateKeyframeV1& k = st.keyframes[i];
+      const auto& kf = ba->keyframes()[i];
+      if ((k.id < 0) != (kf == nullptr)) throw std::runtime_error("keyframe list mismatch");
+      if (!kf) continue;
+      kf->SetActivation(static_cast<Keyframe::Activation>(k.activation));
+      kf->SetLastActiveInBAIteration(k.last_active_in_ba_iteration);
+      kf->SetLastCovisInBAIteration(k.last_covis_in_ba_iteration);
+      kf->set_global_T_frame(st.frame_global_T_frame.at(static_cast<size_t>(k.frame_index)));
+    }
+    ba->SetSurfels(stream, st.surfels.data(), static_cast<size_t>(st.surfels_size) * sizeof(float), static_cast<u32>(st.surfels_size));
+    ba->SetBAIterationCounts(st.ba_iteration_count, st.last_ba_iteration_count);
+  });
+}
+
 // TrackFramePairwise on two keyframes of a DirectBA (base = the reference keyframe, tracked = the frame to localise):
 // out = base_T_tracked.  iterations: num_scales ints (may be null).
 int bsh_track_keyframe_pair(void* ba_, void* stream, int tracked_id, int base_id, int num_scales, int test_different_initial_estimates,

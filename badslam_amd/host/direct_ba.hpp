@@ -227,6 +227,13 @@ class DirectBA {
   bool use_depth_residuals() const { return use_depth_residuals_; }
   bool use_descriptor_residuals() const { return use_descriptor_residuals_; }
   int ba_iteration_count() const { return ba_iteration_count_; }
+  int last_ba_iteration_count() const { return last_ba_iteration_count_; }
+  void SetBAIterationCounts(int count, int last) { ba_iteration_count_ = count; last_ba_iteration_count_ = last; }   // LoadState, BS/io.cc:466-467
+  int max_surfel_count() const { return surfels_->width(); }
+  int min_observation_count_while_bootstrapping_1() const { return min_observation_count_while_bootstrapping_1_; }
+  int min_observation_count_while_bootstrapping_2() const { return min_observation_count_while_bootstrapping_2_; }
+  int min_observation_count() const { return min_observation_count_; }
+  float surfel_merge_dist_factor() const { return surfel_merge_dist_factor_; }
   int GetMinObservationCount() const {   // BS/direct_ba.h:212-218
     return (keyframes_.size() < 10) ? ((keyframes_.size() < 5) ? min_observation_count_while_bootstrapping_1_
                                                               : min_observation_count_while_bootstrapping_2_)

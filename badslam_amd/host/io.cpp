@@ -328,3 +328,187 @@ bool LoadCalibration(const std::string& base, float depth_camera[4], float color
 }
 
 }  // namespace bslam_host
+
+// ------------------------------------------------------------------------------------------------
+// state file v1 (BS/io.cc:38-536)
+// ------------------------------------------------------------------------------------------------
+namespace bslam_host {
+namespace {
+
+struct Writer {
+  FILE* f;
+  void i32(int32_t v) { std::fwrite(&v, 4, 1, f); }
+  void u32(uint32_t v) { std::fwrite(&v, 4, 1, f); }
+  void f32(float v) { std::fwrite(&v, 4, 1, f); }
+  void b(bool v) { const uint8_t u = v ? 1 : 0; std::fwrite(&u, 1, 1, f); }
+  void se3(const SE3f& T) { const float d[7] = {T.qx, T.qy, T.qz, T.qw, T.tx, T.ty, T.tz}; std::fwrite(d, 4, 7, f); }   // Sophus SE3::data(): quaternion coeffs, translation
+  void str(const std::string& s) { u32(static_cast<uint32_t>(s.size())); std::fwrite(s.data(), 1, s.size(), f); }
+};
+struct Reader {
+  FILE* f;
+  bool ok = true;
+  template <class T> T get() { T v{}; if (std::fread(&v, sizeof(T), 1, f) != 1) ok = false; return v; }
+  int32_t i32() { return get<int32_t>(); }
+  uint32_t u32() { return get<uint32_t>(); }
+  float f32() { return get<float>(); }
+  bool b() { return get<uint8_t>() != 0; }
+  SE3f se3() {
+    float d[7] = {0, 0, 0, 1, 0, 0, 0};
+    if (std::fread(d, 4, 7, f) != 7) ok = false;
+    SE3f T;
+    T.qx = d[0]; T.qy = d[1]; T.qz = d[2]; T.qw = d[3]; T.tx = d[4]; T.ty = d[5]; T.tz = d[6];
+    return T;
+  }
+  std::string str() {
+    const uint32_t n = u32();
+    if (!ok || n > (1u << 20)) { ok = false; return std::string(); }
+    std::string s(n, '\0');
+    if (n && std::fread(&s[0], 1, n, f) != n) ok = false;
+    return s;
+  }
+};
+
+void save_config(Writer& w, const BadSlamConfigV1& c) {   // BS/bad_slam_config.cc:47-96
+  w.f32(c.raw_to_float_depth); w.i32(c.start_frame); w.i32(c.end_frame); w.f32(c.target_frame_rate); w.i32(c.fps_restriction);
+  w.i32(c.pyramid_level_for_depth); w.i32(c.pyramid_level_for_color); w.f32(c.max_depth); w.f32(c.baseline_fx);
+  w.i32(c.median_filter_and_densify_iterations); w.f32(c.bilateral_filter_sigma_xy); w.f32(c.bilateral_filter_radius_factor);
+  w.f32(c.bilateral_filter_sigma_inv_depth); w.i32(c.max_surfel_count); w.i32(c.sparse_surfel_cell_size); w.f32(c.surfel_merge_dist_factor);
+  w.i32(c.min_observation_count_while_bootstrapping_1); w.i32(c.min_observation_count_while_bootstrapping_2); w.i32(c.min_observation_count);
+  w.i32(c.num_scales); w.b(c.use_motion_model); w.i32(c.keyframe_interval); w.i32(c.max_num_ba_iterations_per_keyframe);
+  w.b(c.disable_deactivation); w.b(c.use_geometric_residuals); w.b(c.use_photometric_residuals); w.b(c.optimize_intrinsics);
+  w.i32(c.intrinsics_optimization_interval); w.b(c.do_surfel_updates); w.b(c.parallel_ba); w.b(c.use_pcg); w.b(c.estimate_poses);
+  w.i32(c.min_free_gpu_memory_mb); w.b(c.enable_loop_detection); w.b(c.parallel_loop_detection); w.str(c.loop_detection_vocabulary_path);
+  w.str(c.loop_detection_pattern_path); w.f32(c.loop_detection_image_frequency); w.i32(c.loop_detection_images_width);
+  w.i32(c.loop_detection_images_height);
+}
+void load_config(Reader& r, BadSlamConfigV1* c) {   // BS/bad_slam_config.cc:98-200
+  c->raw_to_float_depth = r.f32(); c->start_frame = r.i32(); c->end_frame = r.i32(); c->target_frame_rate = r.f32(); c->fps_restriction = r.i32();
+  c->pyramid_level_for_depth = r.i32(); c->pyramid_level_for_color = r.i32(); c->max_depth = r.f32(); c->baseline_fx = r.f32();
+  c->median_filter_and_densify_iterations = r.i32(); c->bilateral_filter_sigma_xy = r.f32(); c->bilateral_filter_radius_factor = r.f32();
+  c->bilateral_filter_sigma_inv_depth = r.f32(); c->max_surfel_count = r.i32(); c->sparse_surfel_cell_size = r.i32(); c->surfel_merge_dist_factor = r.f32();
+  c->min_observation_count_while_bootstrapping_1 = r.i32(); c->min_observation_count_while_bootstrapping_2 = r.i32(); c->min_observation_count = r.i32();
+  c->num_scales = r.i32(); c->use_motion_model = r.b(); c->keyframe_interval = r.i32(); c->max_num_ba_iterations_per_keyframe = r.i32();
+  c->disable_deactivation = r.b(); c->use_geometric_residuals = r.b(); c->use_photometric_residuals = r.b(); c->optimize_intrinsics = r.b();
+  c->intrinsics_optimization_interval = r.i32(); c->do_surfel_updates = r.b(); c->parallel_ba = r.b(); c->use_pcg = r.b(); c->estimate_poses = r.b();
+  c->min_free_gpu_memory_mb = r.i32(); c->enable_loop_detection = r.b(); c->parallel_loop_detection = r.b(); c->loop_detection_vocabulary_path = r.str();
+  c->loop_detection_pattern_path = r.str(); c->loop_detection_image_frequency = r.f32(); c->loop_detection_images_width = r.i32();
+  c->loop_detection_images_height = r.i32();
+}
+constexpr int32_t kPinholeCamera4fType = 1;   // Camera::Type::kPinholeCamera4f (LV/camera.h:289)
+
+}  // namespace
+
+bool SaveState(const StateV1& s, const std::string& path) {
+  if (s.motion_model_base_kf_tr_frame.size() > 1000 || s.queued_keyframes_frame_indices.size() != s.queued_keyframes_last_kf_tr_this_kf.size() ||
+      s.cfactor.size() != static_cast<size_t>(s.cfactor_width) * s.cfactor_height || s.surfels.size() != static_cast<size_t>(8) * s.surfels_size)
+    return false;
+  FILE* file = std::fopen(path.c_str(), "wb");
+  if (!file) return false;
+  Writer w{file};
+  std::fwrite("BADSLAM", 1, 7, file);
+  const uint8_t version = 1;
+  std::fwrite(&version, 1, 1, file);
+  w.i32(s.base_kf_id);
+  w.u32(static_cast<uint32_t>(s.motion_model_base_kf_tr_frame.size()));
+  for (const SE3f& T : s.motion_model_base_kf_tr_frame) w.se3(T);
+  w.u32(static_cast<uint32_t>(s.queued_keyframes_frame_indices.size()));
+  for (size_t i = 0; i < s.queued_keyframes_frame_indices.size(); ++i) { w.i32(s.queued_keyframes_frame_indices[i]); w.se3(s.queued_keyframes_last_kf_tr_this_kf[i]); }
+  w.i32(s.last_frame_index);
+  save_config(w, s.config);
+  w.u32(static_cast<uint32_t>(s.frame_global_T_frame.size()));
+  for (const SE3f& T : s.frame_global_T_frame) w.se3(T);
+  w.i32(kPinholeCamera4fType); w.i32(s.color_camera_width); w.i32(s.color_camera_height); w.i32(4);
+  std::fwrite(s.color_camera_parameters, 4, 4, file);
+  w.i32(s.pyramid_level_for_color);
+  w.i32(kPinholeCamera4fType); w.i32(s.depth_camera_width); w.i32(s.depth_camera_height); w.i32(4);
+  std::fwrite(s.depth_camera_parameters, 4, 4, file);
+  w.i32(s.cfactor_width); w.i32(s.cfactor_height);
+  w.i32(s.cfactor_width * static_cast<int32_t>(sizeof(float)));   // Image<float>::stride() in bytes; written unpadded
+  std::fwrite(s.cfactor.data(), 4, s.cfactor.size(), file);
+  w.f32(s.a); w.f32(s.raw_to_float_depth); w.f32(s.baseline_fx); w.i32(s.sparse_surfel_cell_size);
+  w.i32(static_cast<int32_t>(s.keyframes.size()));
+  for (const StateKeyframeV1& k : s.keyframes) {
+    w.i32(k.id);
+    if (k.id >= 0) { w.i32(k.frame_index); w.i32(k.activation); w.i32(k.last_active_in_ba_iteration); w.i32(k.last_covis_in_ba_iteration); }
+  }
+  w.i32(s.surfel_count); w.i32(s.surfels_size);
+  std::fwrite(s.surfels.data(), 4, s.surfels.size(), file);
+  w.i32(s.ba_iteration_count); w.i32(s.last_ba_iteration_count);
+  w.b(s.use_depth_residuals); w.b(s.use_descriptor_residuals);
+  w.i32(s.min_observation_count_while_bootstrapping_1); w.i32(s.min_observation_count_while_bootstrapping_2); w.i32(s.min_observation_count);
+  w.f32(s.surfel_merge_dist_factor);
+  const bool ok = !std::ferror(file);
+  std::fclose(file);
+  return ok;
+}
+
+bool LoadState(const std::string& path, StateV1* s, std::string* error) {
+  auto fail = [&](const char* msg) { if (error) *error = msg; return false; };
+  FILE* file = std::fopen(path.c_str(), "rb");
+  if (!file) return fail("cannot open the state file");
+  struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{file};
+  char id[7];
+  if (std::fread(id, 1, 7, file) != 7 || std::memcmp(id, "BADSLAM", 7) != 0) return fail("File identifier does not match.");
+  uint8_t version = 0;
+  if (std::fread(&version, 1, 1, file) != 1 || version != 1) return fail("Unknown file format version.");
+  Reader r{file};
+  s->base_kf_id = r.i32();
+  uint32_t n = r.u32();
+  if (!r.ok || n > 1000) return fail("Unexpected motion model size.");          // BS/io.cc:263-266
+  s->motion_model_base_kf_tr_frame.resize(n);
+  for (uint32_t i = 0; i < n; ++i) s->motion_model_base_kf_tr_frame[i] = r.se3();
+  n = r.u32();
+  if (!r.ok || n > 10000) return fail("Unexpected queued keyframe count.");     // :273-276
+  s->queued_keyframes_frame_indices.resize(n);
+  s->queued_keyframes_last_kf_tr_this_kf.resize(n);
+  for (uint32_t i = 0; i < n; ++i) { s->queued_keyframes_frame_indices[i] = r.i32(); s->queued_keyframes_last_kf_tr_this_kf[i] = r.se3(); }
+  s->last_frame_index = r.i32();
+  load_config(r, &s->config);
+  n = r.u32();
+  if (!r.ok || n > (1u << 24)) return fail("Unexpected frame count.");
+  s->frame_global_T_frame.resize(n);
+  for (uint32_t i = 0; i < n; ++i) s->frame_global_T_frame[i] = r.se3();
+  for (int cam = 0; cam < 2; ++cam) {
+    const int32_t type = r.i32(), w = r.i32(), h = r.i32(), count = r.i32();
+    if (!r.ok || type != kPinholeCamera4fType || count != 4) return fail("Only PinholeCamera4f cameras are supported.");   // :311-316
+    float* p = cam == 0 ? s->color_camera_parameters : s->depth_camera_parameters;
+    if (std::fread(p, 4, 4, file) != 4) return fail("Unexpected end of file.");
+    if (cam == 0) { s->color_camera_width = w; s->color_camera_height = h; s->pyramid_level_for_color = r.i32(); }
+    else { s->depth_camera_width = w; s->depth_camera_height = h; }
+  }
+  s->cfactor_width = r.i32();
+  s->cfactor_height = r.i32();
+  const int32_t stride = r.i32();
+  if (!r.ok || s->cfactor_width <= 0 || s->cfactor_height <= 0 || stride < s->cfactor_width * 4 || stride > 100000 * 4) return fail("Unexpected cfactor buffer size.");
+  s->cfactor.assign(static_cast<size_t>(s->cfactor_width) * s->cfactor_height, 0.f);
+  std::vector<uint8_t> row(static_cast<size_t>(stride));
+  for (int y = 0; y < s->cfactor_height; ++y) {
+    if (std::fread(row.data(), 1, row.size(), file) != row.size()) return fail("Unexpected end of file.");
+    std::memcpy(&s->cfactor[static_cast<size_t>(y) * s->cfactor_width], row.data(), static_cast<size_t>(s->cfactor_width) * 4);
+  }
+  s->a = r.f32(); s->raw_to_float_depth = r.f32(); s->baseline_fx = r.f32(); s->sparse_surfel_cell_size = r.i32();
+  const int32_t kf_count = r.i32();
+  if (!r.ok || kf_count < 0 || static_cast<size_t>(kf_count) > s->frame_global_T_frame.size()) return fail("Unexpected keyframe count.");   // :359-362
+  s->keyframes.assign(static_cast<size_t>(kf_count), StateKeyframeV1());
+  for (int32_t i = 0; i < kf_count; ++i) {
+    StateKeyframeV1& k = s->keyframes[static_cast<size_t>(i)];
+    k.id = r.i32();
+    if (k.id >= 0) {
+      if (k.id != i) return fail("Keyframe ids must equal their position.");     // :384-387
+      k.frame_index = r.i32(); k.activation = r.i32(); k.last_active_in_ba_iteration = r.i32(); k.last_covis_in_ba_iteration = r.i32();
+    }
+  }
+  s->surfel_count = r.i32();
+  s->surfels_size = r.i32();
+  if (!r.ok || s->surfels_size < 0 || s->surfel_count < 0 || s->surfel_count > s->surfels_size) return fail("Unexpected surfel counts.");
+  s->surfels.resize(static_cast<size_t>(8) * s->surfels_size);
+  if (!s->surfels.empty() && std::fread(s->surfels.data(), 4, s->surfels.size(), file) != s->surfels.size()) return fail("Unexpected end of file.");
+  s->ba_iteration_count = r.i32(); s->last_ba_iteration_count = r.i32();
+  s->use_depth_residuals = r.b(); s->use_descriptor_residuals = r.b();
+  s->min_observation_count_while_bootstrapping_1 = r.i32(); s->min_observation_count_while_bootstrapping_2 = r.i32(); s->min_observation_count = r.i32();
+  s->surfel_merge_dist_factor = r.f32();
+  if (!r.ok) return fail("Unexpected end of file.");
+  return true;
+}
+
+}  // namespace bslam_host

@@ -303,3 +303,27 @@ def test_save_and_load_calibration_through_direct_ba(oracle, tmp_path):
     c2, d2, a2 = other.intrinsics()
     assert np.allclose(c1, c2, atol=2e-3) and np.allclose(d1, d2, atol=2e-3) and abs(a1 - a2) < 1e-7   # 6 significant digits in the files
     assert np.array_equal(other.cfactor(scene.cfactor.shape), ba.cfactor(scene.cfactor.shape))
+
+
+def test_save_and_load_state_through_direct_ba(oracle, tmp_path):
+    """The DirectBA part of SaveState / LoadState (BS/io.cc:38-536): after a few BA iterations the state goes to a
+    version-1 file; a fresh DirectBA with the same keyframe images continues from it exactly like the original."""
+    scene = scenes.synthetic_scene(3, seed=8, cell=4)
+    rng = np.random.default_rng(1)
+    for kf in scene.keyframes[1:]:
+        kf.global_T_frame = bso.se3_mul(kf.global_T_frame, bso.se3_exp(np.concatenate([rng.uniform(-0.003, 0.003, 3), rng.uniform(-0.001, 0.001, 3)]).astype(np.float32)))
+    ba = make_ba(scene)
+    ba.BundleAdjustment(False, False, False, True, True, 2, 2, False, 0, 2, True)
+    ba.SaveState(tmp_path / "s.state", frame_count=3)
+    other = make_ba(scene)                      # same images, the scene's (unoptimised) poses and surfels
+    other.LoadState(tmp_path / "s.state")
+    assert other.surfels_size() == ba.surfels_size()
+    assert np.array_equal(other.GetSurfels(8).view(np.uint32), ba.GetSurfels(8).view(np.uint32))
+    for k in range(3):
+        assert np.array_equal(bso.se3_to_np(other.keyframe_pose(k)), bso.se3_to_np(ba.keyframe_pose(k)))
+    # both continue identically
+    ba.BundleAdjustment(False, False, False, True, True, 1, 1, False, 0, 2, True)
+    other.BundleAdjustment(False, False, False, True, True, 1, 1, False, 0, 2, True)
+    assert np.array_equal(other.GetSurfels(8).view(np.uint32), ba.GetSurfels(8).view(np.uint32))
+    for k in range(3):
+        assert np.array_equal(bso.se3_to_np(other.keyframe_pose(k)), bso.se3_to_np(ba.keyframe_pose(k)))

@@ -131,3 +131,68 @@ def test_calibration_files_round_trip(tmp_path):
     assert np.allclose(cf2, cf, rtol=1e-7, atol=1e-10)
     with pytest.raises(dba.DirectBAError):
         dba.load_calibration_arrays(tmp_path / "calib", (6, 9))                     # size mismatch (BS/io.cc:676-679)
+
+
+def reference_state_file_bytes(rng, n_frames=5, n_kf=3, n_surfels=7, cf_w=4, cf_h=3, cf_stride_pad=8):
+    """A version-1 state file written field by field in the order of SaveState (BS/io.cc:38-178) and
+    BadSlamConfig::Save (BS/bad_slam_config.cc:47-96), independently of the C++ writer under test."""
+    out = bytearray(b"BADSLAM" + bytes([1]))
+    i32 = lambda v: out.extend(struct.pack("<i", v))
+    u32 = lambda v: out.extend(struct.pack("<I", v))
+    f32 = lambda v: out.extend(struct.pack("<f", v))
+    b8 = lambda v: out.extend(bytes([1 if v else 0]))
+    se3 = lambda: out.extend(rng.standard_normal(7).astype("<f4").tobytes())
+    s = lambda t: (u32(len(t)), out.extend(t))
+    i32(2)                                   # base_kf_id
+    u32(2); se3(); se3()                      # motion model
+    u32(1); i32(4); se3()                     # queued keyframes
+    i32(4)                                   # last_frame_index
+    f32(0.0002); i32(0); i32(100); f32(0.0); i32(30); i32(0); i32(0); f32(3.0); f32(40.0); i32(0); f32(3.0); f32(2.0); f32(0.005)
+    i32(25000000); i32(4); f32(0.8); i32(1); i32(2); i32(2); i32(5); b8(1); i32(10); i32(10); b8(0); b8(1); b8(1); b8(0); i32(10); b8(1); b8(1); b8(0)
+    b8(1); i32(250); b8(1); b8(1); s(b"/path/to/vocabulary.yml.gz"); s(b"pattern.yml"); f32(0.5); i32(640); i32(480)
+    u32(n_frames)
+    for _ in range(n_frames):
+        se3()
+    i32(1); i32(640); i32(480); i32(4); out.extend(np.array([525.0, 526.0, 320.0, 240.0], "<f4").tobytes()); i32(0)
+    i32(1); i32(640); i32(480); i32(4); out.extend(np.array([524.0, 523.0, 321.0, 239.0], "<f4").tobytes())
+    stride = cf_w * 4 + cf_stride_pad          # Image<float> rows may be padded: the reader must honour the stride
+    i32(cf_w); i32(cf_h); i32(stride)
+    cf = rng.uniform(-0.01, 0.01, (cf_h, cf_w)).astype("<f4")
+    for y in range(cf_h):
+        out.extend(cf[y].tobytes() + bytes(cf_stride_pad))
+    f32(0.0125); f32(0.0002); f32(40.0); i32(4)
+    i32(n_kf)
+    for k in range(n_kf):
+        if k == 1:
+            i32(-1)                            # a deleted keyframe: id only
+        else:
+            i32(k); i32(k + 1); i32(k % 3); i32(7); i32(6)
+    i32(n_surfels); i32(n_surfels)
+    out.extend(rng.standard_normal((8, n_surfels)).astype("<f4").tobytes())
+    i32(9); i32(8); b8(1); b8(0); i32(1); i32(2); i32(2); f32(0.8)
+    return bytes(out), cf
+
+
+def test_state_file_v1_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    data, cf = reference_state_file_bytes(rng, cf_stride_pad=0)
+    (tmp_path / "in.state").write_bytes(data)
+    ints, floats = dba.state_file_round_trip(tmp_path / "in.state", tmp_path / "out.state")
+    assert list(ints) == [2, 4, 5, 3, 7, 7, 9, 4]
+    assert np.allclose(floats, [0.0125, 0.0002, 40.0, 524.0, 523.0, 321.0, 239.0, 525.0, 526.0, 320.0, 240.0])
+    assert (tmp_path / "out.state").read_bytes() == data                      # byte-identical: every field read and written in order
+    # a padded cfactor stride is accepted on load and written back unpadded
+    padded, _ = reference_state_file_bytes(np.random.default_rng(5), cf_stride_pad=8)
+    (tmp_path / "padded.state").write_bytes(padded)
+    dba.state_file_round_trip(tmp_path / "padded.state", tmp_path / "out2.state")
+    assert (tmp_path / "out2.state").read_bytes() == data
+    # corrupt headers / truncated files are rejected
+    (tmp_path / "bad.state").write_bytes(b"BADSLAN" + data[7:])
+    with pytest.raises(dba.DirectBAError):
+        dba.state_file_round_trip(tmp_path / "bad.state", tmp_path / "x")
+    (tmp_path / "v2.state").write_bytes(data[:7] + bytes([2]) + data[8:])
+    with pytest.raises(dba.DirectBAError):
+        dba.state_file_round_trip(tmp_path / "v2.state", tmp_path / "x")
+    (tmp_path / "short.state").write_bytes(data[:-5])
+    with pytest.raises(dba.DirectBAError):
+        dba.state_file_round_trip(tmp_path / "short.state", tmp_path / "x")
