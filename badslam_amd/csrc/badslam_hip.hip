@@ -704,7 +704,15 @@ int bslam_optimize_geometry_iteration(
   const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
   {
   ProfScope prof(ctx, stream, 1);
-  if (!use_descriptor_residuals) hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  if (!use_descriptor_residuals) {
+    // at most one resident grid per launch (5 workgroups of 256 threads per CU at this kernel's register count), so that the
+    // workgroups of a launch walk the keyframe table in near lockstep
+    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * 5) / 8u);   // slots per XCD and launch
+    for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
+      const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
+      hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), dim3(8u * n), block, 0, stream, c, kfs, keyframe_count, sc, first, rows);
+    }
+  }
   else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   }

@@ -278,10 +278,13 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
 // table in near lockstep and the XCD's L2 serves the records of the few keyframes in flight (a grid that needs a
 // second round of workgroups runs two phases of the table at once).  Per-surfel sums are still formed in keyframe
 // order: same bits as the R = 1 kernel.
+// Larger surfel counts are covered by several launches of at most one resident grid each (first_i = first slot of every
+// XCD's range handled by this launch).
 template <int R>
-__global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
+__global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, uint32_t first_i,
+                                                               SurfelRowsRW s) {
   uint32_t slot;
-  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  if (!slot_of_block(sc, blockIdx.x + (first_i << 3), &slot)) return;
   uint32_t idx[R];
   bool on[R];
   f3 gp[R], gn[R];
