@@ -277,13 +277,23 @@ __device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, floa
 __device__ __forceinline__ f2 project_sample(float fx, float fy, float cx, float cy, f3 p) {
   return f2{fx * sdiv(p.x, p.z) + cx, fy * sdiv(p.y, p.z) + cy};
 }
-__device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_squared, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
+// The two tangent sample points gp + t1, gp + t2 depend on the surfel only; the per-pair work is their projection.
+__device__ __forceinline__ void tangent_points(f3 gp, f3 gn, float radius_squared, f3* p1, f3* p2) {
   f3 t1 = cross(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
   t1 = scale3(ssqrt(sdiv(radius_squared, fmaxf(1e-12f, sqlen(t1)))), scale3(2.0f, t1));
-  *t1_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t1)));
+  *p1 = add3(gp, t1);
   f3 t2 = cross(gn, t1);
   t2 = scale3(ssqrt(sdiv(radius_squared, fmaxf(1e-12f, sqlen(t2)))), scale3(2.0f, t2));
-  *t2_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, add3(gp, t2)));
+  *p2 = add3(gp, t2);
+}
+__device__ __forceinline__ void project_tangent_points(f3 p1, f3 p2, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
+  *t1_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, p1));
+  *t2_pxy = project_sample(c.cfx, c.cfy, c.ccx, c.ccy, mul34(T, p2));
+}
+__device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_squared, const M34& T, const CamConsts& c, f2* t1_pxy, f2* t2_pxy) {
+  f3 p1, p2;
+  tangent_points(gp, gn, radius_squared, &p1, &p2);
+  project_tangent_points(p1, p2, T, c, t1_pxy, t2_pxy);
 }
 
 // BS/cost_function.cuh:140-156

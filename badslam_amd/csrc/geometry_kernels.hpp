@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
   if (kMode == 2) {
     // ---- joint position + descriptor step (BS/kernel_opt_geometry.cu:118-231, 273-361)
     float A0 = 0, A1 = 0, A2 = 0, A3 = 0, A5 = 0, A6 = 0, A7 = 0, A8 = 0;   // A4 = H(1,2) is never accumulated (quirk Q2)
-    const float r2 = s.radius_squared[i];
     const float desc1 = s.d1[i], desc2 = s.d2[i];
+    f3 tp1, tp2;
+    tangent_points(gp, gn, s.radius_squared[i], &tp1, &tp2);
     for (int k = 0; k < kf_count; ++k) {
       const KfDev& kf = kfs[k];
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       f2 color_pxy;
       if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
         f2 t1, t2;
-        tangent_projections(gp, gn, r2, kf.frame_T_global, c, &t1, &t2);
+        project_tangent_points(tp1, tp2, kf.frame_T_global, c, &t1, &t2);
         float r1, rr2, gx1, gy1, gx2, gy2;
         descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
         const float term1 = -c.cfx * (rn.x * p.local.z - rn.z * p.local.x);

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
   bool valid[kPoseR];
-  float r2[kPoseR], d1[kPoseR], d2[kPoseR];
+  float d1[kPoseR], d2[kPoseR];
+  f3 tp1[kPoseR], tp2[kPoseR];   // tangent sample points of the descriptor residual (per surfel, not per pair)
 #pragma unroll
   for (int r = 0; r < kPoseR; ++r) {
     const uint32_t i = surfel_of_slot(sc, slot, r, kPoseR);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
     const uint32_t j = valid[r] ? i : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
-    if (kDesc) { r2[r] = s.radius_squared[j]; d1[r] = s.d1[j]; d2[r] = s.d2[j]; }
+    if (kDesc) { d1[r] = s.d1[j]; d2[r] = s.d2[j]; tangent_points(gp[r], gn[r], s.radius_squared[j], &tp1[r], &tp2[r]); }
   }
 
   for (int k = kf_begin; k < kf_end; ++k) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
         f2 color_pxy;
         if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
           f2 t1, t2;
-          tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
+          project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
           float r1, rr2, gx1, gy1, gx2, gy2;
           descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           gx1 *= c.cfx; gx2 *= c.cfx;
