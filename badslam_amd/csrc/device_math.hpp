@@ -344,11 +344,11 @@ __device__ __forceinline__ void descriptor_jacobian_wrt_projected_position(const
 __device__ __forceinline__ void point_value_and_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* value, float* dx, float* dy) {
   const TexFootprint f = tex_footprint(c, p.x, p.y);
   const GradFootprint g = grad_footprint(c, p);
-  const uint32_t q = quad_at(kf, c, f.i, f.j);
-  uint32_t qg = q;
-  if (g.ix != f.i || g.iy != f.j) qg = quad_at(kf, c, g.ix, g.iy);
-  *value = tex_filter(unpack_quad(q), f.a, f.b);
-  grad_filter(unpack_quad(qg), g, dx, dy);
+  const LumaQuad t = unpack_quad(quad_at(kf, c, f.i, f.j));
+  LumaQuad tg = t;
+  if (g.ix != f.i || g.iy != f.j) tg = unpack_quad(quad_at(kf, c, g.ix, g.iy));   // only in the half-pixel border strip
+  *value = tex_filter(t, f.a, f.b);
+  grad_filter(tg, g, dx, dy);
 }
 
 // raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers
