@@ -279,7 +279,7 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
 
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
-                                  int* tiles_out, bool final_sum = true) {
+                                  int* tiles_out, bool reduce_rows = true) {
   Schedule sc;
   const int R = use_desc ? kPoseRDesc : kPoseRGeo;
   int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &sc);
@@ -305,21 +305,15 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   }
   BSLAM_HIP_TRY(hipGetLastError());
+  if (!reduce_rows) return BSLAM_OK;   // the caller's pose_reduce_solve_kernel sums the rows itself
   float* parts = partials + partial_floats;
   // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a part
   // at most rows * 256 -- exact in fp32 up to 2^24, i.e. up to 65k rows per part (134M surfels per keyframe)
   hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count, kReduceParts), dim3(256), 0, stream, (const float*)partials, rows_per_kf, kf_count, parts, states);
   BSLAM_HIP_TRY(hipGetLastError());
-  if (final_sum) {   // otherwise the caller's pose_final_solve_kernel adds the parts itself
-    hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
-    BSLAM_HIP_TRY(hipGetLastError());
-  }
+  hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
+  BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
-}
-
-// Device address of the stage-A parts [K][kReduceParts][kRow] written by launch_pose_accumulate.
-static const float* pose_parts_ptr(const bslam_context* ctx, int tiles, int kf_count) {
-  return (const float*)ctx->partials.ptr + (size_t)tiles * (kPoseThreads / 64) * kf_count * kRow;
 }
 
 }  // namespace bslam
@@ -581,8 +575,8 @@ int bslam_estimate_frame_poses_batched(
       int tiles = 0;
       int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false);
       if (r) return r;
-      hipLaunchKernelGGL(pose_final_solve_kernel, dim3((unsigned)keyframe_count), dim3(64), 0, stream, pose_parts_ptr(ctx, tiles, keyframe_count),
-                         keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
+      hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
+                         tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
       BSLAM_HIP_TRY(hipGetLastError());
     } else {
       if (surfels_size > 0) {

@@ -292,13 +292,17 @@ __device__ inline void se3_inverse_matrix(Quat q, f3 t, float* m /*12*/) {
 
 // 6x6 symmetric solve in double: LDL^T with diagonal pivoting (what Eigen's
 // selfadjointView<Upper>().ldlt().solve() does at BS/direct_ba_alternating.cc:206).
-__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x) {
+// The pivoting makes the indexing dynamic, which would put A / y / perm into scratch memory (global latency on every
+// access of a serial fp64 chain); the caller provides an LDS workspace instead.
+struct LdltWork { double A[36]; double temp[6]; double y[6]; int perm[6]; };
+
+__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x, LdltWork* ws) {
   constexpr int n = 6;
-  double A[36];
+  double* A = ws->A;
   int idx = 0;
   for (int r = 0; r < n; ++r)
     for (int cc = r; cc < n; ++cc) { A[r * n + cc] = (double)H_upper[idx]; A[cc * n + r] = (double)H_upper[idx]; ++idx; }
-  int perm[n];
+  int* perm = ws->perm;
   for (int k = 0; k < n; ++k) {
     int p = k;
     double biggest = fabs(A[k * n + k]);
@@ -308,7 +312,7 @@ __device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* 
       for (int cc = 0; cc < n; ++cc) { const double tmp = A[k * n + cc]; A[k * n + cc] = A[p * n + cc]; A[p * n + cc] = tmp; }
       for (int r = 0; r < n; ++r) { const double tmp = A[r * n + k]; A[r * n + k] = A[r * n + p]; A[r * n + p] = tmp; }
     }
-    double temp[n];
+    double* temp = ws->temp;
     for (int j = 0; j < k; ++j) temp[j] = A[j * n + j] * A[k * n + j];
     double acc = 0.0;
     for (int j = 0; j < k; ++j) acc += A[k * n + j] * temp[j];
@@ -321,7 +325,7 @@ __device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* 
       A[i * n + k] = (fabs(dk) > 0.0) ? v / dk : 0.0;
     }
   }
-  double y[n];
+  double* y = ws->y;
   for (int i = 0; i < n; ++i) y[i] = (double)b[i];
   for (int k = 0; k < n; ++k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
   for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
@@ -347,10 +351,11 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
   if (k >= kf_count) return;
   PoseState st = states[k];
   if (st.converged) return;
+  __shared__ LdltWork work[64];
   float H[21], b[6], x[6];
   for (int i = 0; i < 21; ++i) H[i] = coeffs[(size_t)k * kRow + i];
   for (int i = 0; i < 6; ++i) b[i] = coeffs[(size_t)k * kRow + 21 + i];
-  solve_ldlt6(H, b, x);
+  solve_ldlt6(H, b, x, &work[threadIdx.x]);
   float neg[6];
   for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
   Quat dq; f3 dt;
@@ -371,18 +376,39 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
   if (!st.converged) atomicAdd(active_count, 1);
 }
 
-// pose_reduce_final_kernel + pose_solve_kernel in one launch (single-GPU path: no exchange between the
-// two): block k adds the stage-A parts of keyframe k into LDS, thread 0 solves and updates the pose.
-__global__ __launch_bounds__(64) void pose_final_solve_kernel(const float* __restrict__ parts, int kf_count, PoseState* __restrict__ states,
-                                                             KfDev* __restrict__ kfs, int* __restrict__ active_count) {
+// pose_reduce_kernel + pose_reduce_final_kernel + pose_solve_kernel in one launch (single-GPU path: no exchange in
+// between).  Block k sums the per-wave rows [rows][32] of keyframe k -- thread (sub, col) owns the rows r = sub mod 32 of
+// column col and keeps four independent partial sums for memory-level parallelism; the 32 per-thread sums of a column
+// are then added in a fixed order (deterministic) -- and thread 0 does the fp64 pivoted LDL^T, the SE3 update and the
+// convergence test with its workspace in LDS.
+constexpr int kReduceSolveThreads = 1024;
+__global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
+                                                                               PoseState* __restrict__ states, KfDev* __restrict__ kfs,
+                                                                               int* __restrict__ active_count) {
   const int k = blockIdx.x;
   if (states[k].converged) return;   // uniform
+  __shared__ float sm[32][kRow];
   __shared__ float row[kRow];
-  const int col = threadIdx.x;
-  if (col < 27) {
+  __shared__ LdltWork work;
+  const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const float* base = partials + (size_t)k * rows_per_kf * kRow + col;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int r = sub;
+  for (; r + 96 < rows_per_kf; r += 128) {
+    v0 += base[(size_t)r * kRow];
+    v1 += base[(size_t)(r + 32) * kRow];
+    v2 += base[(size_t)(r + 64) * kRow];
+    v3 += base[(size_t)(r + 96) * kRow];
+  }
+  if (r < rows_per_kf) v0 += base[(size_t)r * kRow];
+  if (r + 32 < rows_per_kf) v1 += base[(size_t)(r + 32) * kRow];
+  if (r + 64 < rows_per_kf) v2 += base[(size_t)(r + 64) * kRow];
+  sm[sub][col] = ((v0 + v1) + v2) + v3;
+  __syncthreads();
+  if (threadIdx.x < 27) {
     float total = 0.f;
-    for (int p = 0; p < kReduceParts; ++p) total += parts[((size_t)k * kReduceParts + p) * kRow + col];
-    row[col] = total;
+    for (int i = 0; i < 32; ++i) total += sm[i][threadIdx.x];
+    row[threadIdx.x] = total;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -390,7 +416,7 @@ __global__ __launch_bounds__(64) void pose_final_solve_kernel(const float* __res
   float H[21], b[6], x[6];
   for (int i = 0; i < 21; ++i) H[i] = row[i];
   for (int i = 0; i < 6; ++i) b[i] = row[21 + i];
-  solve_ldlt6(H, b, x);
+  solve_ldlt6(H, b, x, &work);
   float neg[6];
   for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
   Quat dq; f3 dt;
