@@ -570,13 +570,15 @@ int bslam_estimate_frame_poses_batched(
   // unconverged on its way to h_active[it % 4].
   auto enqueue_iteration = [&](int it) -> int {
     const int slot = it & 3;
-    BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
-    if (surfels_size > 0 && !allreduce) {
+    const bool fused = surfels_size > 0 && !allreduce;
+    // Fused path: the previous iteration's reduce+solve kernel already zeroed this slot.
+    if (!fused || it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
+    if (fused) {
       int tiles = 0;
       int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false);
       if (r) return r;
       hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
-                         tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
+                         tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
       BSLAM_HIP_TRY(hipGetLastError());
     } else {
       if (surfels_size > 0) {

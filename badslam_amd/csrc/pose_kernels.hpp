@@ -384,8 +384,9 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
 constexpr int kReduceSolveThreads = 1024;
 __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                                PoseState* __restrict__ states, KfDev* __restrict__ kfs,
-                                                                               int* __restrict__ active_count) {
+                                                                               int* __restrict__ active_count, int* __restrict__ next_active_count) {
   const int k = blockIdx.x;
+  if (k == 0 && threadIdx.x == 0) *next_active_count = 0;   // the next iteration's counter (last read four iterations ago)
   if (states[k].converged) return;   // uniform
   __shared__ float sm[32][kRow];
   __shared__ float row[kRow];
