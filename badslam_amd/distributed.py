@@ -54,7 +54,13 @@ class AllReduceHook:
             else:
                 arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(count,))
                 t = self.torch.from_numpy(arr)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.device and stream:
+                # The library enqueued the producers on `stream`: make it torch's current stream for the call, so
+                # the collective is ordered after them and the library's next kernels after the collective.
+                with self.torch.cuda.stream(self.torch.cuda.ExternalStream(stream)):
+                    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            else:   # the NULL stream is torch's default stream
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             self.calls += 1
             return 0
         except Exception as e:  # never let an exception cross the C boundary

@@ -55,7 +55,11 @@ def _worker(rank, world, port, out_dir):
     shard.keyframes = scene.keyframes
     hip = gpu_util.Hip(shard.to_device("cuda:0"))
     hook = AllReduceHook(device=True)
-    poses, iters, conv = hip.estimate_poses_batched(init, allreduce=hook.callback)
+    # rank 1 runs the library on a side stream: the hook must order the collective on the stream it is handed
+    import contextlib
+    torch.cuda.synchronize()
+    with (torch.cuda.stream(torch.cuda.Stream()) if rank == 1 else contextlib.nullcontext()):
+        poses, iters, conv = hip.estimate_poses_batched(init, allreduce=hook.callback)
     assert hook.calls >= 2
     np.save(os.path.join(out_dir, f"poses_{rank}.npy"), _pose_array(poses))
     np.save(os.path.join(out_dir, f"iters_{rank}.npy"), np.array(iters))
