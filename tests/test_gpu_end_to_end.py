@@ -86,3 +86,13 @@ def test_tum_directory_to_bundle_adjusted_poses(oracle, tmp_path):
     dba.save_poses([f["depth_timestamp"] for f in ds["frames"]], poses7, 0, tmp_path / "poses.txt")
     back = (tmp_path / "poses.txt").read_text().splitlines()
     assert len(back) == K + 1 and back[1].split()[0] == ds["frames"][0]["depth_timestamp"]
+
+    # accuracy as SURVEY.md 8(d) defines it: ATE RMSE of the exported trajectory against groundtruth.txt.
+    # K = 6 poses around one spot, so the rigid alignment absorbs part of the start error; BA still has to win clearly.
+    from badslam_amd import ate
+    start7 = np.array([dba.pose7(T) for T in start], np.float32)
+    dba.save_poses([f["depth_timestamp"] for f in ds["frames"]], start7, 0, tmp_path / "poses_start.txt")
+    ate_start = ate.ate_files(tmp_path / "groundtruth.txt", tmp_path / "poses_start.txt")
+    ate_ba = ate.ate_files(tmp_path / "groundtruth.txt", tmp_path / "poses.txt")
+    assert ate_start["pairs"] == ate_ba["pairs"] == K
+    assert ate_ba["rmse"] < 2e-4 and ate_ba["rmse"] < 0.2 * ate_start["rmse"], (ate_start["rmse"], ate_ba["rmse"])
