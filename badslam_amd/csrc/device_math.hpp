@@ -532,10 +532,26 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
-// Sums 32 per-lane values across the 64 lanes of a wave with 32 exchanges instead of 32 x 6:
-// at every step a lane keeps one half of its values and trades the other half with lane ^ mask, so
+// Sums 32 per-lane values across the 64 lanes of a wave with 31 exchanges instead of 32 x 6:
+// at every step a lane keeps one half of its values and trades the other half with a partner lane, so
 // the value count halves while the number of lanes summed doubles.  Afterwards lane l holds the
 // wave total of column (l >> 1) & 31 (both lanes of a pair hold it).  Fixed tree: deterministic.
+// The exchanges across rows of 16 lanes go through ds_bpermute; those inside a row are DPP operands of
+// the add (row_ror:8, row_half_mirror, quad_perm).  gfx950's v_permlane32_swap / v_permlane16_swap for
+// the first two steps (85 instead of 190 instructions) measured the same kernel time, so the builtin-only
+// form stays.
+__device__ __forceinline__ float dpp_add_ror8(float keep, float send) {
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_add_half_mirror(float keep, float send) {
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x141, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_add_xor2(float keep, float send) {   // quad_perm:[2,3,0,1]
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4e, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_add_xor1(float keep, float send) {   // quad_perm:[1,0,3,2]
+  return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xb1, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   const uint32_t lane = threadIdx.x & 63u;
 #define BSLAM_TR_STEP(N, MASK)                                           \
@@ -549,11 +565,22 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   }
   BSLAM_TR_STEP(16, 32)
   BSLAM_TR_STEP(8, 16)
-  BSLAM_TR_STEP(4, 8)
-  BSLAM_TR_STEP(2, 4)
-  BSLAM_TR_STEP(1, 2)
 #undef BSLAM_TR_STEP
-  return v[0] + __shfl_xor(v[0], 1, 64);
+  {
+    const bool up = (lane & 8u) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = dpp_add_ror8(up ? v[i + 4] : v[i], up ? v[i] : v[i + 4]);
+  }
+  {
+    const bool up = (lane & 4u) != 0;    // partner = lane ^ 7 inside each group of 8
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = dpp_add_half_mirror(up ? v[i + 2] : v[i], up ? v[i] : v[i + 2]);
+  }
+  {
+    const bool up = (lane & 2u) != 0;
+    v[0] = dpp_add_xor2(up ? v[1] : v[0], up ? v[0] : v[1]);
+  }
+  return dpp_add_xor1(v[0], v[0]);
 }
 
 // Generic form for N = 8 or 16 values: N - 1 exchanges down to one value per lane, then log2(64 / N)

@@ -71,8 +71,15 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
   for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fmaf(wr, J[i], acc[21 + i]);
 }
 
+// Occupancy target handed to the register allocator: without it the 32 accumulators' zero initialisation lands in a
+// second 32-register tuple (104 VGPRs, 4 waves per SIMD); with it the geometric kernel fits 76 VGPRs (6 waves).
+// The photometric variants need ~122 VGPRs (4 waves).
+#ifndef BSLAM_POSE_WAVES_GEO
+#define BSLAM_POSE_WAVES_GEO 6
+#endif
+#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? 4 : BSLAM_POSE_WAVES_GEO)))
 template <bool kDepth, bool kDesc, int kPoseR>
-__global__ __launch_bounds__(kPoseThreads) void pose_accumulate_kernel(
+__global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
     SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states) {
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
