@@ -459,14 +459,20 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
 // Depth residual and its pose Jacobian (BS/kernel_opt_pose.cu:45-94, BS/cost_function.cuh:56-88).
 __device__ __forceinline__ void depth_residual_and_jacobian(const CamConsts& c, const Proj& r, float* raw, float* J) {
   const float inv_stddev = depth_inv_stddev(nx_of(c, (float)r.px), ny_of(c, (float)r.py), r.depth, r.n_local, c.baseline_fx);
-  const f3 lu = unproject(c, r.px, r.py, r.depth);
-  *raw = inv_stddev * dot(r.n_local, sub3(lu, r.local));
-  J[0] = inv_stddev * r.n_local.x;
-  J[1] = inv_stddev * r.n_local.y;
-  J[2] = inv_stddev * r.n_local.z;
-  J[3] = inv_stddev * (-r.n_local.y * lu.z + r.n_local.z * lu.y);
-  J[4] = inv_stddev * (r.n_local.x * lu.z - r.n_local.z * lu.x);
-  J[5] = inv_stddev * (-r.n_local.x * lu.y + r.n_local.y * lu.x);
+  {
+    // Past the association test nothing feeds an integer output any more: residual and Jacobian may use fused
+    // multiply-adds (as the reference's nvcc build does by default); the predicate path stays unfused.
+#pragma clang fp contract(fast)
+    const f3 lu = mk3(r.depth * (c.fx_inv * r.px + c.cx_inv), r.depth * (c.fy_inv * r.py + c.cy_inv), r.depth);
+    const f3 dl = mk3(lu.x - r.local.x, lu.y - r.local.y, lu.z - r.local.z);
+    *raw = inv_stddev * (r.n_local.x * dl.x + r.n_local.y * dl.y + r.n_local.z * dl.z);
+    J[0] = inv_stddev * r.n_local.x;
+    J[1] = inv_stddev * r.n_local.y;
+    J[2] = inv_stddev * r.n_local.z;
+    J[3] = inv_stddev * (-r.n_local.y * lu.z + r.n_local.z * lu.y);
+    J[4] = inv_stddev * (r.n_local.x * lu.z - r.n_local.z * lu.x);
+    J[5] = inv_stddev * (-r.n_local.x * lu.y + r.n_local.y * lu.x);
+  }
 }
 
 // Pose Jacobian of one descriptor residual (BS/kernel_opt_pose.cu:122-141).

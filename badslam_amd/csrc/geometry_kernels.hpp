@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
   const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
   const f3 gn = unpack_normal(s.normal[i]);
   for (int k = 0; k < kf_count; ++k) {
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];
     if (kf.activation != BSLAM_KF_ACTIVE) continue;
     Proj p;
     if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; break; }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void count_pairs_kernel(CamConsts c, const KfD
     const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
     const f3 gn = unpack_normal(s.normal[i]);
     for (int k = 0; k < kf_count; ++k) {
-      const KfDev& kf = kfs[k];
+      const KfDev kf = kfs[k];
       const M34& T = kf.frame_T_global;
       f3 l;
       l.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
   {
     float sx = 0, sy = 0, sz = 0, cnt = 0;
     for (int k = 0; k < kf_count; ++k) {
-      const KfDev& kf = kfs[k];
+      const KfDev kf = kfs[k];
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     // ---- position along the normal from depth residuals (BS/kernel_opt_geometry.cu:417-459, 487-507)
     float H = 0, b = 0;
     for (int k = 0; k < kf_count; ++k) {
-      const KfDev& kf = kfs[k];
+      const KfDev kf = kfs[k];
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     f3 tp1, tp2;
     tangent_points(gp, gn, s.radius_squared[i], &tp1, &tp2);
     for (int k = 0; k < kf_count; ++k) {
-      const KfDev& kf = kfs[k];
+      const KfDev kf = kfs[k];
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
 #pragma unroll
     for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
     for (int k = 0; k < kf_count; ++k) {
-      const KfDev& kf = kfs[k];
+      const KfDev kf = kfs[k];
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       const float* Rm = kf.global_R_frame;
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
 #pragma unroll
   for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
   for (int k = 0; k < kf_count; ++k) {
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];
     if (kf.activation == BSLAM_KF_INACTIVE) continue;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

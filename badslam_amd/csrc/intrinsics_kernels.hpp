@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
   for (int i = 0; i < kIntrRow; ++i) acc[i] = 0.f;
 
   for (int k = 0; k < kf_count; ++k) {
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];
 #pragma unroll
     for (int r = 0; r < kIntrR; ++r) {
       Proj p;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 
   int parity = 0;
   for (int k = 0; k < kf_count; ++k) {
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pose[kPcgPoseRow];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
 
   int parity = 0;
   for (int k = 0; k < kf_count; ++k) {
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pp[6] = {0, 0, 0, 0, 0, 0};

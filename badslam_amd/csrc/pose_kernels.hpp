@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
 
   for (int k = kf_begin; k < kf_end; ++k) {
     if (states != nullptr && states[k].converged) continue;   // uniform
-    const KfDev& kf = kfs[k];
+    const KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
     float acc[kRow];
 #pragma unroll
     for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
