@@ -167,7 +167,7 @@ def main():
                    "in_bounds_pair_fraction": frac_inb, "associated_pair_fraction": assoc.value / pairs_per_pass,
                    "parallelism": f"surfel-shard x{world}"},
         "roofline": {"bound": "hbm", "kernel": "pose_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(use_desc, "pose_accumulate_kernel"),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(use_desc, "pose_accumulate_kernel", K, S),
                      "avg_launch_us": avg_launch_s * 1e6, "launches": launches.value,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "geometry_kernel": geometry_roofline(S, K, frac_inb, assoc.value / pairs_per_pass, use_desc, glaunches.value, gms.value)},
@@ -181,13 +181,17 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(use_desc, kernel):
+def pmc_traffic(use_desc, kernel, K, S):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written
     from tools/pmc.sh runs of this same command; counters cannot be read from inside the timed process), or None."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["photo" if use_desc else "geo"].get(kernel)
+            j = json.load(f)
+        w = j.get("workload", {})
+        if (w.get("keyframes"), w.get("surfels_per_gpu")) != (K, S):
+            return None   # the counters were collected on another workload
+        return j["photo" if use_desc else "geo"].get(kernel)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -201,7 +205,7 @@ def geometry_roofline(S, K, frac_inb, frac_assoc, use_desc, launches, total_ms):
     avg_s = total_ms / 1e3 / launches
     ach = nbytes / avg_s / 1e9
     return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": nbytes,
-            "traffic": pmc_traffic(use_desc, "geometry_kernel")}
+            "traffic": pmc_traffic(use_desc, "geometry_kernel", K, S)}
 
 
 def host_cpu_share():
