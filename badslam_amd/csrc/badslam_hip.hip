@@ -306,12 +306,10 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   }
   BSLAM_HIP_TRY(hipGetLastError());
   if (!reduce_rows) return BSLAM_OK;   // the caller's pose_reduce_solve_kernel sums the rows itself
-  float* parts = partials + partial_floats;
-  // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a part
-  // at most rows * 256 -- exact in fp32 up to 2^24, i.e. up to 65k rows per part (134M surfels per keyframe)
-  hipLaunchKernelGGL(pose_reduce_kernel, dim3((unsigned)kf_count, kReduceParts), dim3(256), 0, stream, (const float*)partials, rows_per_kf, kf_count, parts, states);
-  BSLAM_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(pose_reduce_final_kernel, dim3((unsigned)kf_count), dim3(64), 0, stream, (const float*)parts, kf_count, (float*)ctx->coeffs.ptr, states);
+  // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a thread's
+  // share at most rows / 32 * 256 -- exact in fp32 up to 2^24
+  hipLaunchKernelGGL(pose_reduce_rows_kernel, dim3((unsigned)kf_count), dim3(1024), 0, stream, (const float*)partials, rows_per_kf, kf_count,
+                     (float*)ctx->coeffs.ptr, states);
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -571,8 +569,8 @@ int bslam_estimate_frame_poses_batched(
   auto enqueue_iteration = [&](int it) -> int {
     const int slot = it & 3;
     const bool fused = surfels_size > 0 && !allreduce;
-    // Fused path: the previous iteration's reduce+solve kernel already zeroed this slot.
-    if (!fused || it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
+    // Later slots are zeroed by the previous iteration's solve kernel.
+    if (it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
     if (fused) {
       int tiles = 0;
       int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false);
@@ -591,13 +589,12 @@ int bslam_estimate_frame_poses_batched(
         BSLAM_HIP_TRY(hipMemsetAsync(ctx->coeffs.ptr, 0, (size_t)keyframe_count * kRow * sizeof(float), stream));   // H.setZero(); b.setZero() (:147-149)
       }
       if (allreduce) {
-        // converged keyframes keep stale rows; they are identical on every rank because every rank
-        // applied identical updates, and the solve kernel ignores them.
+        // rows of converged keyframes are zeros on every rank; the solve kernel ignores them.
         const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
         if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
       }
       hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
-                         (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot);
+                         (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
       BSLAM_HIP_TRY(hipGetLastError());
     }
     BSLAM_HIP_TRY(hipMemcpyAsync(h_active + slot, d_active + slot, sizeof(int), hipMemcpyDeviceToHost, stream));

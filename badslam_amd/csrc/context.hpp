@@ -119,7 +119,9 @@ struct bslam_context {
   bslam::Slab coeffs;        // float[K][32]
   bslam::Slab pose_state;    // PoseState[K]
   bslam::Slab misc;          // small device scalars
-  bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step
+  bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step; or the PCG path's fp64 cell sums
+  int intr_cells_owner = 0;  // 0: intrinsics step (zeroes per call), 1: PCG (kept zero between calls)
+  size_t intr_cells_cells = 0;
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
   bslam::StagingRing upload_ring;   // keyframe table / pose state uploads

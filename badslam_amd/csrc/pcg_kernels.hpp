@@ -41,6 +41,12 @@ struct PcgParams {
   uint32_t shard_begin, shard_end;
   float* r; float* M; float* delta; float* g; float* p;
   float* alpha_n; float* alpha_d; float* beta_n;
+  // Sums over the pairs that fall into one cfactor cell (library scratch, zero on entry): formed with fp64 atomics
+  // and rounded to fp32 once by pcg_cf_flush_kernel.  The reference adds floats atomically in arrival order
+  // (BS/kernel_pcg.cu: atomicAddFloatOrDouble), which makes whole BA runs differ from one run to the next; in
+  // fp64 the order only matters below 1e-16 relative, so the rounded sums are the same on every run.
+  double* cf_acc0; double* cf_acc1;
+  uint32_t cf_cells;
 };
 
 __device__ __forceinline__ uint32_t kf_pose_unknown_index(int gauge, int id) {   // BS/direct_ba_pcg.cc:329-337
@@ -190,8 +196,9 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
               glob[5 + j] += t.d[j] * wj;
             }
             const float wj = weight * t.cf_jac;
-            atomicAdd(&P.r[t.cf_index], -1 * wj * raw);
-            atomicAdd(&P.M[t.cf_index], t.cf_jac * wj);
+            const uint32_t cell = t.cf_index - (P.depth_intr_start + 5);
+            atomicAdd(&P.cf_acc0[cell], (double)(-1 * wj * raw));
+            atomicAdd(&P.cf_acc1[cell], (double)(t.cf_jac * wj));
           } else {
             visible = false;                                      // :272 (also disables the descriptor part)
           }
@@ -301,6 +308,21 @@ __global__ __launch_bounds__(kPcgPoseReduceThreads) void pcg_pose_reduce_kernel(
   } else {
     if (col < 6) P.g[kf_idx + col] = total;
   }
+}
+
+// Rounds the fp64 cell sums into the unknown vectors (mode 0: r, M; mode 1: g) and leaves the scratch zero.
+__global__ __launch_bounds__(256) void pcg_cf_flush_kernel(PcgParams P, int mode) {
+  const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= P.cf_cells) return;
+  const uint32_t idx = P.depth_intr_start + 5 + cell;
+  if (mode == 0) {
+    P.r[idx] += (float)P.cf_acc0[cell];
+    P.M[idx] += (float)P.cf_acc1[cell];
+    P.cf_acc1[cell] = 0.0;
+  } else {
+    P.g[idx] += (float)P.cf_acc0[cell];
+  }
+  P.cf_acc0[cell] = 0.0;
 }
 
 // Sums the per-tile global rows.  mode 0: init -> r, M of the intrinsics; mode 1: step1 -> alpha_d and g.
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
         if (kIntr && P.optimize_depth_intr && t.valid) {
 #pragma unroll
           for (int j = 0; j < 5; ++j) glob[1 + j] += t.d[j] * sum;
-          atomicAdd(&P.g[t.cf_index], t.cf_jac * sum);
+          atomicAdd(&P.cf_acc0[t.cf_index - (P.depth_intr_start + 5)], (double)(t.cf_jac * sum));
         }
       }
       if (kDesc) {

@@ -208,6 +208,46 @@ __global__ __launch_bounds__(64) void pose_reduce_final_kernel(const float* __re
   }
 }
 
+// Both stages in one launch for the batched loop with an all-reduce hook: block k (1024 threads) sums keyframe k's
+// rows coalesced in the same fixed order as pose_reduce_solve_kernel and writes the coefficient row that goes through
+// the exchange (count as two exact 16-bit halves, as above).  Rows of converged keyframes are written as zeros, so
+// that repeated in-place all-reduces never grow stale values.
+__global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
+                                                               float* __restrict__ coeffs, const PoseState* __restrict__ states) {
+  const int k = blockIdx.x;
+  if (states != nullptr && states[k].converged) {
+    if (threadIdx.x < kRow) coeffs[(size_t)k * kRow + threadIdx.x] = 0.f;
+    return;
+  }
+  __shared__ float sm[32][kRow];
+  const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const float* base = partials + (size_t)k * rows_per_kf * kRow + col;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int r = sub;
+  for (; r + 96 < rows_per_kf; r += 128) {
+    v0 += base[(size_t)r * kRow];
+    v1 += base[(size_t)(r + 32) * kRow];
+    v2 += base[(size_t)(r + 64) * kRow];
+    v3 += base[(size_t)(r + 96) * kRow];
+  }
+  if (r < rows_per_kf) v0 += base[(size_t)r * kRow];
+  if (r + 32 < rows_per_kf) v1 += base[(size_t)(r + 32) * kRow];
+  if (r + 64 < rows_per_kf) v2 += base[(size_t)(r + 64) * kRow];
+  sm[sub][col] = ((v0 + v1) + v2) + v3;   // the count column: <= 256 per row, exact in fp32 up to 65k rows
+  __syncthreads();
+  if (threadIdx.x >= kRow) return;
+  if (col == kRowCount) {
+    uint32_t total = 0;
+    for (int i = 0; i < 32; ++i) total += (uint32_t)sm[i][col];
+    coeffs[(size_t)k * kRow + kRowCount] = (float)(total & 0xffffu);
+    coeffs[(size_t)k * kRow + kRowCount + 1] = (float)(total >> 16);
+  } else if (col != kRowCount + 1) {
+    float total = 0.f;
+    for (int i = 0; i < 32; ++i) total += sm[i][col];
+    coeffs[(size_t)k * kRow + col] = total;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SE3 (Sophus::SE3f semantics: unit quaternion + translation, fp32) and the 6x6 solve
 // ---------------------------------------------------------------------------------------------
@@ -353,8 +393,9 @@ __global__ void pose_init_kernel(int kf_count, const PoseState* __restrict__ sta
 
 // One Gauss-Newton update per keyframe (BS/direct_ba_alternating.cc:206-233).
 __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count, PoseState* __restrict__ states,
-                                  KfDev* __restrict__ kfs, int* __restrict__ active_count) {
+                                  KfDev* __restrict__ kfs, int* __restrict__ active_count, int* __restrict__ next_active_count) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && next_active_count != nullptr) *next_active_count = 0;   // last read four iterations ago
   if (k >= kf_count) return;
   PoseState st = states[k];
   if (st.converged) return;
