@@ -22,8 +22,19 @@ struct IntrinsicsCells {
   float* D;          // [cells]
   float* b2;         // [cells]
   uint32_t* obs;     // [cells]
+  double* acc;       // [7][cells]: B, D, b2 summed with fp64 atomics, rounded into the float arrays by intrinsics_cells_round_kernel
   int cells;
 };
+
+// The reference adds floats atomically in arrival order (BS/kernel_opt_intrinsics.cu:176-196); the fp64 sums make the
+// rounded blocks, and with them whole BA runs, the same on every run.
+__global__ __launch_bounds__(256) void intrinsics_cells_round_kernel(IntrinsicsCells cells) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= cells.cells) return;
+  for (int q = 0; q < 5; ++q) cells.B[(size_t)q * cells.cells + cell] = (float)cells.acc[(size_t)q * cells.cells + cell];
+  cells.D[cell] = (float)cells.acc[(size_t)5 * cells.cells + cell];
+  cells.b2[cell] = (float)cells.acc[(size_t)6 * cells.cells + cell];
+}
 
 template <bool kDepthIntr, bool kColorIntr>
 __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
@@ -87,9 +98,9 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
           for (int i = 0; i < 5; ++i) acc[15 + i] += wr * dj[i];
           const int cell = sparse_px + sparse_py * c.cfactor_width;
 #pragma unroll
-          for (int q = 0; q < 5; ++q) atomicAdd(&cells.B[(size_t)q * cells.cells + cell], w * dj[q] * dj[5]);
-          atomicAdd(&cells.D[cell], w * dj[5] * dj[5]);
-          atomicAdd(&cells.b2[cell], w * raw * dj[5]);
+          for (int q = 0; q < 5; ++q) atomicAdd(&cells.acc[(size_t)q * cells.cells + cell], (double)(w * dj[q] * dj[5]));
+          atomicAdd(&cells.acc[(size_t)5 * cells.cells + cell], (double)(w * dj[5] * dj[5]));
+          atomicAdd(&cells.acc[(size_t)6 * cells.cells + cell], (double)(w * raw * dj[5]));
           atomicAdd(&cells.obs[cell], 1u);
         }
       }

@@ -173,7 +173,7 @@ def test_two_ranks_sharded_bundle_adjustment(tmp_path, oracle, use_pcg, depth_in
         dz = np.abs(got[:3] - surfels[:3, lo:hi]).max(axis=0)
         # surfel updates are ~3 mm here; a few surfels sit at an association threshold and flip with the
         # (slightly different) poses, everything else agrees to a fraction of a percent of the update
-        # (PCG + depth deformation: the cfactor cells are accumulated with float atomics, as in the reference, so
-        # that case also varies run to run; its bar is the same 5 % of the ~3 mm update as the pose bar above)
+        # (PCG + depth deformation: the weakly constrained cfactor cells amplify the different summation partition of the
+        # two shards; its bar is the same 5 % of the ~3 mm update as the pose bar above)
         q_bar, max_bar = (3e-4, 1e-3) if (use_pcg and depth_intr) else (2e-5, 5e-4)
         assert np.quantile(dz, 0.999) < q_bar and dz.max() < max_bar, (rank, float(np.quantile(dz, 0.999)), float(dz.max()))
