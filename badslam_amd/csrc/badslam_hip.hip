@@ -47,6 +47,7 @@ static CamConsts make_cam_consts(const bslam_context* ctx, const bslam_camera4f*
   c.a = dp->a;
   c.raw_to_float_depth = dp->raw_to_float_depth;
   c.baseline_fx = dp->baseline_fx;
+  c.inv_baseline_fx = 1.0f / dp->baseline_fx;   // IEEE single division on the host, as in the CPU oracle
   c.cell = dp->sparse_surfel_cell_size;
   c.cfactor = (const float*)dp->cfactor_buffer.address;
   c.cfactor_pitch = (uint32_t)dp->cfactor_buffer.pitch;

@@ -58,7 +58,7 @@ struct CamConsts {
   // colour camera (corner convention; the centre projector only differs in cx, cy which are unused)
   float cfx, cfy, ccx, ccy;
   // DepthParameters scalars
-  float a, raw_to_float_depth, baseline_fx;
+  float a, raw_to_float_depth, baseline_fx, inv_baseline_fx;
   int cell;
   const float* cfactor;   // device image
   uint32_t cfactor_pitch; // bytes
@@ -91,7 +91,10 @@ __device__ __forceinline__ f3 unproject(const CamConsts& c, int x, int y, float 
   return mk3(depth * (c.fx_inv * x + c.cx_inv), depth * (c.fy_inv * y + c.cy_inv), depth);
 }
 __device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3 p) {                       // BS/surfel_projection.cuh:52
-  return f2{fx * (p.x / p.z) + cx, fy * (p.y / p.z) + cy};
+  // one correctly rounded reciprocal + two multiplies (the CPU oracle's projection has the same shape; the reference's
+  // -use_fast_math build evaluates p.x / p.z as p.x * rcp(p.z))
+  const float inv_z = 1.0f / p.z;
+  return f2{fx * (p.x * inv_z) + cx, fy * (p.y * inv_z) + cy};
 }
 
 // exp(x) from plain fp32 multiplies and adds (Cephes expf: Cody-Waite reduction by ln 2, degree-5 polynomial,
@@ -169,9 +172,11 @@ __device__ __forceinline__ float rrcp(float b) { return 1.f / b; }
 #endif
 #if BSLAM_FAST_RESIDUAL_MATH >= 2
 __device__ __forceinline__ float sdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float srcp(float b) { return __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #else
 __device__ __forceinline__ float sdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float srcp(float b) { return 1.0f / b; }
 __device__ __forceinline__ float ssqrt(float x) { return sqrtf(x); }
 #endif
 
@@ -197,8 +202,8 @@ constexpr float kCosNormalCompat = 0.76604f;   // BS/kernels.cuh:58
 constexpr float kDescWeight = 1e-2f;
 constexpr float kDescHuber = 10.f;
 
-__device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
-  return (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
+__device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, f3 n, float inv_baseline_fx) {   // inv_baseline_fx = fl(1 / baseline_fx)
+  return (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) * inv_baseline_fx;
 }
 __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
   return rdiv(baseline_fx, kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
@@ -275,7 +280,8 @@ __device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, floa
 
 // BS/cost_function.cuh:115-136
 __device__ __forceinline__ f2 project_sample(float fx, float fy, float cx, float cy, f3 p) {
-  return f2{fx * sdiv(p.x, p.z) + cx, fy * sdiv(p.y, p.z) + cy};
+  const float inv_z = srcp(p.z);
+  return f2{fx * (p.x * inv_z) + cx, fy * (p.y * inv_z) + cy};
 }
 // The two tangent sample points gp + t1, gp + t2 depend on the surfel only; the per-pair work is their projection.
 __device__ __forceinline__ void tangent_points(f3 gp, f3 gn, float radius_squared, f3* p1, f3* p2) {
@@ -443,7 +449,7 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   r->depth = __uint_as_float(rec.x);
   r->raw_depth = rec.y >> 16;
   r->n_local = rot34(T, gn);
-  const float stddev = depth_stddev(nx_of(c, (float)r->px), ny_of(c, (float)r->py), r->depth, r->n_local, c.baseline_fx);
+  const float stddev = depth_stddev(nx_of(c, (float)r->px), ny_of(c, (float)r->py), r->depth, r->n_local, c.inv_baseline_fx);
   if (fabsf(r->local.z - r->depth) > kDepthTukey * stddev) return false;
   // reference: (1.0f / Norm(local)) * Dot(local, n_local) > 0  (:107-111).  1 / |local| is a positive,
   // finite, normal number for every |local| in [2^-126, 2^126] (and |local| >= local.z > 0 here), so the

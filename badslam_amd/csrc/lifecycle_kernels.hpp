@@ -43,7 +43,7 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t h) { return __half2
 template <bool kFreeSpace>
 __device__ __forceinline__ bool association_tail(const CamConsts& c, f3 local, f3 n_local, int px, int py, float pixel_depth,
                                                  uint32_t pixel_normal, bool* fsv) {
-  const float stddev = depth_stddev(nx_of(c, (float)px), ny_of(c, (float)py), pixel_depth, n_local, c.baseline_fx);
+  const float stddev = depth_stddev(nx_of(c, (float)px), ny_of(c, (float)py), pixel_depth, n_local, c.inv_baseline_fx);
   const float thr = kDepthTukey * stddev;
   if (kFreeSpace) {
     const float diff = pixel_depth - local.z;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
           if (pixel_depth > 0) {
             // IsAssociatedWithPixel<false>(… image normals …) BS/surfel_projection_nvcc_only.cuh:168-215
             n_local = rot34(T, u16_to_image_space_normal(im.surfel_normals.at<uint16_t>(y, x)));
-            const float stddev = depth_stddev(nx_of(c, (float)px), ny_of(c, (float)py), pixel_depth, n_local, c.baseline_fx);
+            const float stddev = depth_stddev(nx_of(c, (float)px), ny_of(c, (float)py), pixel_depth, n_local, c.inv_baseline_fx);
             visible = !(fabsf(local.z - pixel_depth) > (threshold_factor * kDepthTukey) * stddev) && !(dot(local, n_local) > 0) &&
                       !(dot(n_local, u16_to_image_space_normal(im.frame_normals.at<uint16_t>(py, px))) < kCosNormalCompat);
           }

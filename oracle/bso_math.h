@@ -100,9 +100,13 @@ static inline bso_f3 bso_unproject(const bso_unprojector* u, int x, int y, float
   return bso_make3(depth * (u->fx_inv * x + u->cx_inv), depth * (u->fy_inv * y + u->cy_inv), depth);
 }
 static inline bso_f2 bso_project(float fx, float fy, float cx, float cy, bso_f3 p) {        /* BS/surfel_projection.cuh:52-55 */
+  /* The reference writes p.x / p.z and p.y / p.z and builds with -use_fast_math (BS/CMakeLists.txt:67), under which
+     nvcc evaluates a / b as a * rcp(b).  The restatement takes that shape with a correctly rounded reciprocal, so
+     that CPU and GPU agree to the last bit at one division per projection. */
+  const float inv_z = 1.0f / p.z;
   bso_f2 r;
-  r.x = fx * (p.x / p.z) + cx;
-  r.y = fy * (p.y / p.z) + cy;
+  r.x = fx * (p.x * inv_z) + cx;
+  r.y = fy * (p.y * inv_z) + cy;
   return r;
 }
 static inline bso_depth_to_color bso_make_depth_to_color(const bslam_camera4f* depth, const bslam_camera4f* color) {
@@ -233,7 +237,9 @@ static inline float bso_huber_weight(float r, float k) {
 #define BSO_COS_NORMAL_COMPAT 0.76604f         /* BS/kernels.cuh:58 */
 
 static inline float bso_depth_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {      /* :81-83 */
-  return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
+  /* ".../ baseline_fx" in the reference; same -use_fast_math shape as bso_project: times the rounded reciprocal */
+  const float inv_baseline_fx = 1.0f / baseline_fx;
+  return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) * inv_baseline_fx;
 }
 static inline float bso_depth_inv_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {  /* :86-88 */
   return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
