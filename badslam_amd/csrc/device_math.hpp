@@ -20,12 +20,19 @@ struct f3 { float x, y, z; };
 struct f2 { float x, y; };
 
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
-__device__ __forceinline__ float sqlen(f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }           // BS/cuda_util.cuh:52
-__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // BS/cuda_util.cuh:57
+// Sums of products are explicit fused multiply-adds in ONE fixed shape shared with the CPU oracle: the reference's nvcc
+// build contracts a * b + c wherever it likes, so no unfused order is "the" reference; an explicit fma chain is exactly
+// defined on CPU and GPU alike (integer outputs stay bit-comparable) at half the instructions.  -ffp-contract=off
+// stays: nothing is fused implicitly.
+__device__ __forceinline__ float sqlen(f3 v) { return __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)); }           // BS/cuda_util.cuh:52
+__device__ __forceinline__ float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }       // BS/cuda_util.cuh:57
+// one row of a rigid transform / of a rotation applied to p
+__device__ __forceinline__ float tr_row(float a, float b, float c, float d, f3 p) { return __builtin_fmaf(c, p.z, __builtin_fmaf(b, p.y, __builtin_fmaf(a, p.x, d))); }
+__device__ __forceinline__ float rot_row(float a, float b, float c, f3 p) { return __builtin_fmaf(c, p.z, __builtin_fmaf(b, p.y, a * p.x)); }
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {                                                     // BS/cuda_util.cuh:78
   return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
-__device__ __forceinline__ float norm3(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }  // BS/cuda_util.cuh:85
+__device__ __forceinline__ float norm3(f3 v) { return sqrtf(sqlen(v)); }                            // BS/cuda_util.cuh:85
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 scale3(float m, f3 b) { return mk3(m * b.x, m * b.y, m * b.z); }
@@ -34,14 +41,10 @@ __device__ __forceinline__ f3 scale3(float m, f3 b) { return mk3(m * b.x, m * b.
 struct M34 { float m[12]; };
 
 __device__ __forceinline__ f3 mul34(const M34& T, f3 p) {
-  return mk3(T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z + T.m[3],
-             T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z + T.m[7],
-             T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z + T.m[11]);
+  return mk3(tr_row(T.m[0], T.m[1], T.m[2], T.m[3], p), tr_row(T.m[4], T.m[5], T.m[6], T.m[7], p), tr_row(T.m[8], T.m[9], T.m[10], T.m[11], p));
 }
 __device__ __forceinline__ f3 rot34(const M34& T, f3 p) {
-  return mk3(T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z,
-             T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z,
-             T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z);
+  return mk3(rot_row(T.m[0], T.m[1], T.m[2], p), rot_row(T.m[4], T.m[5], T.m[6], p), rot_row(T.m[8], T.m[9], T.m[10], p));
 }
 
 // Per-launch camera constants, computed on the host exactly as the reference's factories do
@@ -85,16 +88,16 @@ struct KfDev {
   int id;
 };
 
-__device__ __forceinline__ float nx_of(const CamConsts& c, float px) { return c.fx_inv * px + c.cx_inv; }   // BS/surfel_projection.cuh:116
-__device__ __forceinline__ float ny_of(const CamConsts& c, float py) { return c.fy_inv * py + c.cy_inv; }
+__device__ __forceinline__ float nx_of(const CamConsts& c, float px) { return __builtin_fmaf(c.fx_inv, px, c.cx_inv); }   // BS/surfel_projection.cuh:116
+__device__ __forceinline__ float ny_of(const CamConsts& c, float py) { return __builtin_fmaf(c.fy_inv, py, c.cy_inv); }
 __device__ __forceinline__ f3 unproject(const CamConsts& c, int x, int y, float depth) {                    // BS/surfel_projection.cuh:110
-  return mk3(depth * (c.fx_inv * x + c.cx_inv), depth * (c.fy_inv * y + c.cy_inv), depth);
+  return mk3(depth * nx_of(c, (float)x), depth * ny_of(c, (float)y), depth);
 }
 __device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3 p) {                       // BS/surfel_projection.cuh:52
   // one correctly rounded reciprocal + two multiplies (the CPU oracle's projection has the same shape; the reference's
   // -use_fast_math build evaluates p.x / p.z as p.x * rcp(p.z))
   const float inv_z = 1.0f / p.z;
-  return f2{fx * (p.x * inv_z) + cx, fy * (p.y * inv_z) + cy};
+  return f2{__builtin_fmaf(fx, p.x * inv_z, cx), __builtin_fmaf(fy, p.y * inv_z, cy)};
 }
 
 // exp(x) from plain fp32 multiplies and adds (Cephes expf: Cody-Waite reduction by ln 2, degree-5 polynomial,
@@ -129,7 +132,7 @@ __device__ __forceinline__ f3 u16_to_image_space_normal(uint32_t value) {
   f3 r;
   r.x = (float)(int8_t)(value & 0xff) * (1.0f / 127);
   r.y = (float)(int8_t)((value >> 8) & 0xff) * (1.0f / 127);
-  r.z = 1 - r.x * r.x - r.y * r.y;
+  r.z = __builtin_fmaf(-r.y, r.y, __builtin_fmaf(-r.x, r.x, 1.0f));
   r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
   return r;
 }
@@ -203,10 +206,10 @@ constexpr float kDescWeight = 1e-2f;
 constexpr float kDescHuber = 10.f;
 
 __device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, f3 n, float inv_baseline_fx) {   // inv_baseline_fx = fl(1 / baseline_fx)
-  return (kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) * inv_baseline_fx;
+  return (kDepthUncertainty * fabsf(__builtin_fmaf(n.x, nx, __builtin_fmaf(n.y, ny, n.z))) * (depth * depth)) * inv_baseline_fx;
 }
 __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, f3 n, float baseline_fx) {
-  return rdiv(baseline_fx, kDepthUncertainty * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
+  return rdiv(baseline_fx, kDepthUncertainty * fabsf(__builtin_fmaf(n.x, nx, __builtin_fmaf(n.y, ny, n.z))) * (depth * depth));
 }
 __device__ __forceinline__ float depth_weight(float r) { return 1.f * tukey_weight(r, 1.f * kDepthTukey); }
 __device__ __forceinline__ float weighted_depth_residual(float r) { return 1.f * tukey_residual(r, 1.f * kDepthTukey); }
@@ -281,7 +284,7 @@ __device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, floa
 // BS/cost_function.cuh:115-136
 __device__ __forceinline__ f2 project_sample(float fx, float fy, float cx, float cy, f3 p) {
   const float inv_z = srcp(p.z);
-  return f2{fx * (p.x * inv_z) + cx, fy * (p.y * inv_z) + cy};
+  return f2{__builtin_fmaf(fx, p.x * inv_z, cx), __builtin_fmaf(fy, p.y * inv_z, cy)};
 }
 // The two tangent sample points gp + t1, gp + t2 depend on the surfel only; the per-pair work is their projection.
 __device__ __forceinline__ void tangent_points(f3 gp, f3 gn, float radius_squared, f3* p1, f3* p2) {
@@ -434,10 +437,10 @@ __global__ __launch_bounds__(256) void build_quads_kernel(CamConsts c, const KfD
 __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, Proj* r) {
   const M34& T = kf.frame_T_global;
   // MultiplyIfResultZIsPositive BS/cuda_matrix.cuh:113-124
-  r->local.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+  r->local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
   if (r->local.z <= 0.f) return false;
-  r->local.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
-  r->local.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+  r->local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
+  r->local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
   // ProjectSurfelToImage BS/util.cuh:86-99
   r->pxy = project(c.fx, c.fy, c.cx, c.cy, r->local);
   r->px = f2i(r->pxy.x);

@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void count_pairs_kernel(CamConsts c, const KfD
       const KfDev kf = kfs[k];
       const M34& T = kf.frame_T_global;
       f3 l;
-      l.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+      l.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
       if (l.z <= 0.f) continue;
-      l.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
-      l.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+      l.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
+      l.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
       const f2 pxy = project(c.fx, c.fy, c.cx, c.cy, l);
       if (pxy.x < 0 || pxy.y < 0 || f2i(pxy.x) >= c.width || f2i(pxy.y) >= c.height) continue;
       inb += 1;
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
       const f3 ln = u16_to_image_space_normal(p.pixel_normal);
       const float* R = kf.global_R_frame;
-      sx += R[0] * ln.x + R[1] * ln.y + R[2] * ln.z;
-      sy += R[3] * ln.x + R[4] * ln.y + R[5] * ln.z;
-      sz += R[6] * ln.x + R[7] * ln.y + R[8] * ln.z;
+      sx += rot_row(R[0], R[1], R[2], ln);
+      sy += rot_row(R[3], R[4], R[5], ln);
+      sz += rot_row(R[6], R[7], R[8], ln);
       cnt += 1.f;
     }
     if (cnt >= 1) {
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
         Proj p;
         if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
         const f3 ln = u16_to_image_space_normal(p.pixel_normal);
-        sx[r] += Rm[0] * ln.x + Rm[1] * ln.y + Rm[2] * ln.z;
-        sy[r] += Rm[3] * ln.x + Rm[4] * ln.y + Rm[5] * ln.z;
-        sz[r] += Rm[6] * ln.x + Rm[7] * ln.y + Rm[8] * ln.z;
+        sx[r] += rot_row(Rm[0], Rm[1], Rm[2], ln);
+        sy[r] += rot_row(Rm[3], Rm[4], Rm[5], ln);
+        sz[r] += rot_row(Rm[6], Rm[7], Rm[8], ln);
         cnt[r] += 1.f;
       }
     }

@@ -63,10 +63,10 @@ template <bool kFreeSpace>
 __device__ __forceinline__ bool associate_direct(const CamConsts& c, const KfImages& kf, f3 gp, f3 gn, int* px, int* py, bool* fsv) {
   const M34& T = kf.frame_T_global;
   f3 local;
-  local.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+  local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
   if (local.z <= 0.f) return false;
-  local.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
-  local.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+  local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
+  local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
   const f2 pxy = project(c.fx, c.fy, c.cx, c.cy, local);
   *px = f2i(pxy.x);
   *py = f2i(pxy.y);
@@ -81,10 +81,10 @@ __device__ __forceinline__ bool associate_direct(const CamConsts& c, const KfIma
 __device__ __forceinline__ bool associate_records_fs(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, int* px, int* py, bool* fsv) {
   const M34& T = kf.frame_T_global;
   f3 local;
-  local.z = T.m[8] * gp.x + T.m[9] * gp.y + T.m[10] * gp.z + T.m[11];
+  local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
   if (local.z <= 0.f) return false;
-  local.x = T.m[0] * gp.x + T.m[1] * gp.y + T.m[2] * gp.z + T.m[3];
-  local.y = T.m[4] * gp.x + T.m[5] * gp.y + T.m[6] * gp.z + T.m[7];
+  local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
+  local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
   const f2 pxy = project(c.fx, c.fy, c.cx, c.cy, local);
   *px = f2i(pxy.x);
   *py = f2i(pxy.y);
@@ -292,10 +292,10 @@ __global__ __launch_bounds__(256) void create_filter_kernel(CamConsts c, KfImage
     const KfImages& ck = covis[k];
     const M34& T = covis_T_frame[k];
     f3 local;
-    local.z = T.m[8] * input_position.x + T.m[9] * input_position.y + T.m[10] * input_position.z + T.m[11];
+    local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], input_position);
     if (local.z <= 0.f) continue;
-    local.x = T.m[0] * input_position.x + T.m[1] * input_position.y + T.m[2] * input_position.z + T.m[3];
-    local.y = T.m[4] * input_position.x + T.m[5] * input_position.y + T.m[6] * input_position.z + T.m[7];
+    local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], input_position);
+    local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], input_position);
     const f2 pxy = project(c.fx, c.fy, c.cx, c.cy, local);
     const int px = f2i(pxy.x), py = f2i(pxy.y);
     if (pxy.x < 0 || pxy.y < 0 || px >= c.width || py >= c.height) continue;

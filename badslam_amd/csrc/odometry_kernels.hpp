@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
     float pixel_depth = 0.f;
     if (surfel_depth > 0) {
       const f3 p = unproject(c, x, y, surfel_depth);
-      local.z = T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z + T.m[11];
+      local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], p);
       if (local.z > 0.f) {
-        local.x = T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z + T.m[3];
-        local.y = T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z + T.m[7];
+        local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], p);
+        local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], p);
         pxy = project(c.fx, c.fy, c.cx, c.cy, local);
         px = f2i(pxy.x); py = f2i(pxy.y);
         if (!(pxy.x < 0 || pxy.y < 0 || px >= c.width || py >= c.height)) {

@@ -38,12 +38,21 @@ static inline int bso_f2i(float v) {
 }
 
 /* ---- BS/cuda_util.cuh:52-107 ------------------------------------------------ */
-static inline float bso_sqlen(bso_f3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }           /* :52 */
-static inline float bso_dot(bso_f3 a, bso_f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   /* :57 */
+/* Sums of products are written as explicit fused multiply-adds, in ONE fixed shape shared with the HIP kernels
+ * (csrc/device_math.hpp): the reference's nvcc build contracts a * b + c into FMAs wherever it likes, so no
+ * unfused evaluation order is "the" reference; an explicit fmaf chain is exactly defined on both CPU and GPU
+ * (so the integer outputs stay bit-comparable) and costs the kernels half the instructions.  -ffp-contract=off stays:
+ * nothing is fused implicitly. */
+#define BSO_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+static inline float bso_sqlen(bso_f3 v) { return BSO_FMA(v.z, v.z, BSO_FMA(v.y, v.y, v.x * v.x)); }           /* :52 */
+static inline float bso_dot(bso_f3 a, bso_f3 b) { return BSO_FMA(a.z, b.z, BSO_FMA(a.y, b.y, a.x * b.x)); }   /* :57 */
+/* one row of a rigid transform / of a rotation applied to p */
+static inline float bso_tr_row(float a, float b, float c, float d, bso_f3 p) { return BSO_FMA(c, p.z, BSO_FMA(b, p.y, BSO_FMA(a, p.x, d))); }
+static inline float bso_rot_row(float a, float b, float c, bso_f3 p) { return BSO_FMA(c, p.z, BSO_FMA(b, p.y, a * p.x)); }
 static inline bso_f3 bso_cross(bso_f3 a, bso_f3 b) {                                            /* :78 */
   return bso_make3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
-static inline float bso_norm(bso_f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }     /* :85 */
+static inline float bso_norm(bso_f3 v) { return sqrtf(bso_sqlen(v)); }                           /* :85 */
 static inline bso_f3 bso_add(bso_f3 a, bso_f3 b) { return bso_make3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline bso_f3 bso_sub(bso_f3 a, bso_f3 b) { return bso_make3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline bso_f3 bso_scale(float m, bso_f3 b) { return bso_make3(m * b.x, m * b.y, m * b.z); }
@@ -51,29 +60,23 @@ static inline bso_f3 bso_scale(float m, bso_f3 b) { return bso_make3(m * b.x, m 
 /* ---- BS/cuda_matrix.cuh:98-137 ---------------------------------------------- */
 static inline bso_f3 bso_mul34(const bslam_mat3x4* T, bso_f3 p) {                               /* :98 */
   const float* m = T->m;
-  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
-                   m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
-                   m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+  return bso_make3(bso_tr_row(m[0], m[1], m[2], m[3], p), bso_tr_row(m[4], m[5], m[6], m[7], p), bso_tr_row(m[8], m[9], m[10], m[11], p));
 }
 static inline int bso_mul34_if_z_positive(const bslam_mat3x4* T, bso_f3 p, bso_f3* out) {       /* :113 */
   const float* m = T->m;
-  out->z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+  out->z = bso_tr_row(m[8], m[9], m[10], m[11], p);
   if (out->z <= 0.f) return 0;
-  out->x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
-  out->y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+  out->x = bso_tr_row(m[0], m[1], m[2], m[3], p);
+  out->y = bso_tr_row(m[4], m[5], m[6], m[7], p);
   return 1;
 }
 static inline bso_f3 bso_rotate34(const bslam_mat3x4* T, bso_f3 p) {                            /* :129 */
   const float* m = T->m;
-  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z,
-                   m[4] * p.x + m[5] * p.y + m[6] * p.z,
-                   m[8] * p.x + m[9] * p.y + m[10] * p.z);
+  return bso_make3(bso_rot_row(m[0], m[1], m[2], p), bso_rot_row(m[4], m[5], m[6], p), bso_rot_row(m[8], m[9], m[10], p));
 }
 static inline bso_f3 bso_mul33(const bslam_mat3x3* R, bso_f3 p) {                               /* :64 */
   const float* m = R->m;
-  return bso_make3(m[0] * p.x + m[1] * p.y + m[2] * p.z,
-                   m[3] * p.x + m[4] * p.y + m[5] * p.z,
-                   m[6] * p.x + m[7] * p.y + m[8] * p.z);
+  return bso_make3(bso_rot_row(m[0], m[1], m[2], p), bso_rot_row(m[3], m[4], m[5], p), bso_rot_row(m[6], m[7], m[8], p));
 }
 
 /* ---- pitched buffers (libvis/src/libvis/cuda/cuda_buffer.cuh:61-83) ---------- */
@@ -94,10 +97,10 @@ static inline bso_unprojector bso_make_unprojector(const bslam_camera4f* c) {   
   u.cy_inv = -cy_pixel_center * u.fy_inv;
   return u;
 }
-static inline float bso_unproj_nx(const bso_unprojector* u, float px) { return u->fx_inv * px + u->cx_inv; }  /* BS/surfel_projection.cuh:116 */
-static inline float bso_unproj_ny(const bso_unprojector* u, float py) { return u->fy_inv * py + u->cy_inv; }
+static inline float bso_unproj_nx(const bso_unprojector* u, float px) { return BSO_FMA(u->fx_inv, px, u->cx_inv); }  /* BS/surfel_projection.cuh:116 */
+static inline float bso_unproj_ny(const bso_unprojector* u, float py) { return BSO_FMA(u->fy_inv, py, u->cy_inv); }
 static inline bso_f3 bso_unproject(const bso_unprojector* u, int x, int y, float depth) {   /* BS/surfel_projection.cuh:110-114 */
-  return bso_make3(depth * (u->fx_inv * x + u->cx_inv), depth * (u->fy_inv * y + u->cy_inv), depth);
+  return bso_make3(depth * bso_unproj_nx(u, (float)x), depth * bso_unproj_ny(u, (float)y), depth);
 }
 static inline bso_f2 bso_project(float fx, float fy, float cx, float cy, bso_f3 p) {        /* BS/surfel_projection.cuh:52-55 */
   /* The reference writes p.x / p.z and p.y / p.z and builds with -use_fast_math (BS/CMakeLists.txt:67), under which
@@ -105,8 +108,8 @@ static inline bso_f2 bso_project(float fx, float fy, float cx, float cy, bso_f3 
      that CPU and GPU agree to the last bit at one division per projection. */
   const float inv_z = 1.0f / p.z;
   bso_f2 r;
-  r.x = fx * (p.x * inv_z) + cx;
-  r.y = fy * (p.y * inv_z) + cy;
+  r.x = BSO_FMA(fx, p.x * inv_z, cx);
+  r.y = BSO_FMA(fy, p.y * inv_z, cy);
   return r;
 }
 static inline bso_depth_to_color bso_make_depth_to_color(const bslam_camera4f* depth, const bslam_camera4f* color) {
@@ -166,7 +169,7 @@ static inline bso_f3 bso_u16_to_image_space_normal(uint16_t value) {            
   bso_f3 r;
   r.x = bso_s8_to_small_float((int8_t)(value & 0x00ff));
   r.y = bso_s8_to_small_float((int8_t)((value & 0xff00) >> 8));
-  r.z = 1 - r.x * r.x - r.y * r.y;
+  r.z = BSO_FMA(-r.y, r.y, BSO_FMA(-r.x, r.x, 1.0f));
   r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
   return r;
 }
@@ -239,10 +242,10 @@ static inline float bso_huber_weight(float r, float k) {
 static inline float bso_depth_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {      /* :81-83 */
   /* ".../ baseline_fx" in the reference; same -use_fast_math shape as bso_project: times the rounded reciprocal */
   const float inv_baseline_fx = 1.0f / baseline_fx;
-  return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) * inv_baseline_fx;
+  return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(BSO_FMA(n.x, nx, BSO_FMA(n.y, ny, n.z))) * (depth * depth)) * inv_baseline_fx;
 }
 static inline float bso_depth_inv_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {  /* :86-88 */
-  return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
+  return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(BSO_FMA(n.x, nx, BSO_FMA(n.y, ny, n.z))) * (depth * depth));
 }
 static inline float bso_depth_weight(float r) { return BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_weight(r, 1.f * BSO_DEPTH_TUKEY); }           /* :91-93 */
 static inline float bso_weighted_depth_residual(float r) { return BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_residual(r, 1.f * BSO_DEPTH_TUKEY); }  /* :96-98 */
