@@ -419,6 +419,20 @@ int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float*
   return BSLAM_OK;
 }
 
+int bslam_debug_decode_normals(bslam_context* ctx, void* stream_, float* out_xyz) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ctx || !out_xyz) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)65536 * 3 * sizeof(float);
+  int rc = ctx->coeffs.reserve(bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(decode_normals_kernel, dim3(256), dim3(256), 0, stream, (float*)ctx->coeffs.ptr);
+  BSLAM_HIP_TRY(hipGetLastError());
+  BSLAM_HIP_TRY(hipMemcpyAsync(out_xyz, ctx->coeffs.ptr, bytes, hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  return BSLAM_OK;
+}
+
 int bslam_debug_count_pairs(
     bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
     int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,

@@ -127,13 +127,27 @@ __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor,
   return 1.f / (inv_depth + cfactor * e);
 }
 
+// Correctly rounded sqrt for x == 0 or 2^-96 <= x < 2^96: v_sqrt_f32 (<= 1 ulp) plus the two residual tests of the
+// compiler's general expansion; its rescaling of tiny inputs and the final class test are dead for such x (7 of 15
+// instructions).  Same bits as sqrtf() there.
+__device__ __forceinline__ float sqrt_rn_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x);
+  const float r_up = __builtin_fmaf(-s_up, s, x);
+  float r = (r_dn <= 0.f) ? s_dn : s;
+  r = (r_up > 0.f) ? s_up : r;
+  return r;
+}
+
 // BS/util.cuh:107-130
 __device__ __forceinline__ f3 u16_to_image_space_normal(uint32_t value) {
   f3 r;
   r.x = (float)(int8_t)(value & 0xff) * (1.0f / 127);
   r.y = (float)(int8_t)((value >> 8) & 0xff) * (1.0f / 127);
   r.z = __builtin_fmaf(-r.y, r.y, __builtin_fmaf(-r.x, r.x, 1.0f));
-  r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
+  r.z = -sqrt_rn_midrange((r.z > 0.f) ? r.z : 0.f);   // 0, or >= 2^-25: a difference of numbers in [0, 1] rounded to 2^-24
   return r;
 }
 

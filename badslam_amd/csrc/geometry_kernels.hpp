@@ -72,6 +72,15 @@ __global__ __launch_bounds__(256) void association_kernel(CamConsts c, const KfD
   out[i] = project_and_associate(c, kfs[0], gp, gn, &p) ? (uint32_t)(p.py * c.width + p.px) : 0xffffffffu;
 }
 
+// bslam_debug_decode_normals: every u16 normal code through u16_to_image_space_normal
+__global__ __launch_bounds__(256) void decode_normals_kernel(float* __restrict__ out) {
+  const uint32_t code = blockIdx.x * 256u + threadIdx.x;
+  const f3 n = u16_to_image_space_normal(code);
+  out[3 * code + 0] = n.x;
+  out[3 * code + 1] = n.y;
+  out[3 * code + 2] = n.z;
+}
+
 // Census: pairs passing z > 0 and bounds, and associated pairs (roofline accounting).
 __global__ __launch_bounds__(256) void count_pairs_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s,
                                                           unsigned long long* __restrict__ out) {

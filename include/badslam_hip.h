@@ -310,6 +310,11 @@ int bslam_debug_association(
     uint32_t surfels_size, const bslam_buffer2d* surfels,
     uint32_t* out_pixel);
 
+/* Decodes all 65536 u16 image-space normal codes (BS/util.cuh:120-130) with the kernels' own routine into
+ * HOST out_xyz[65536 * 3]; lets the tests compare the device's correctly rounded z = -sqrt(1 - x^2 - y^2) with the
+ * CPU's bit for bit over the whole domain. */
+int bslam_debug_decode_normals(bslam_context* ctx, void* stream, float* out_xyz);
+
 /* Census for the roofline accounting of SURVEY.md 8(d): number of (surfel, keyframe) pairs
  * that pass the z > 0 and image-bounds tests (pairs that do not stop after 12 bytes), and
  * number of associated pairs.  HOST outputs, valid on return. */

@@ -305,3 +305,29 @@ def test_ragged_surfel_count(hip_mod, oracle):
         got = hip.accumulate_pose(k)
         assert got["count"] == ref["count"]
         assert rel_close(got["H"], ref["H64"])
+
+
+def test_normal_decode_is_correctly_rounded_over_the_whole_domain():
+    """All 65536 u16 normal codes through the kernels' decode (specialised correctly rounded sqrt) against an
+    independent evaluation of BS/util.cuh:120-130 in the oracle's shape: z = -sqrt(max(0, fma(-y, y, fma(-x, x, 1))))."""
+    import ctypes as C
+    import torch
+    import badslam_amd
+    L = badslam_amd.lib()
+    ctx = badslam_amd.Context(0)
+    out = np.zeros((65536, 3), np.float32)
+    badslam_amd.check(L.bslam_debug_decode_normals(ctx.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                   out.ctypes.data_as(C.POINTER(C.c_float))))
+    codes = np.arange(65536, dtype=np.uint32)
+    x = (codes & 0xff).astype(np.uint8).view(np.int8).astype(np.float32) * np.float32(1.0 / 127)
+    y = ((codes >> 8) & 0xff).astype(np.uint8).view(np.int8).astype(np.float32) * np.float32(1.0 / 127)
+    # exact products / sums in 64-bit-mantissa long double (x^2 is a multiple of 2^-60), one rounding per fma
+    xl, yl = x.astype(np.longdouble), y.astype(np.longdouble)
+    assert np.finfo(np.longdouble).nmant >= 63
+    t = (np.longdouble(1) - xl * xl).astype(np.float32)
+    z2 = (t.astype(np.longdouble) - yl * yl).astype(np.float32)
+    z = -np.sqrt(np.maximum(z2, np.float32(0)))
+    assert np.array_equal(out[:, 0].view(np.uint32), x.view(np.uint32))
+    assert np.array_equal(out[:, 1].view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(out[:, 2].view(np.uint32), z.astype(np.float32).view(np.uint32))
+    assert (z2 > 0).sum() > 40000 and (z2 <= 0).sum() > 10000      # both branches of the clamp are exercised
