@@ -279,8 +279,10 @@ __device__ __forceinline__ TexFootprint tex_footprint(const CamConsts& c, float 
     f.a = floorf(f.a * 256.0f + 0.5f) * (1.0f / 256.0f);
     f.b = floorf(f.b * 256.0f + 0.5f) * (1.0f / 256.0f);
   }
-  f.i = (int)fminf(fmaxf(fx, -1.0f), (float)(c.color_width - 1));
-  f.j = (int)fminf(fmaxf(fy, -1.0f), (float)(c.color_height - 1));
+  // clamp = v_med3_f32 (same selection as fminf(fmaxf(.)) for the finite arguments that reach this point, without the
+  // two NaN-quieting moves fminf / fmaxf cost each)
+  f.i = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, (float)(c.color_width - 1));
+  f.j = (int)__builtin_amdgcn_fmed3f(fy, -1.0f, (float)(c.color_height - 1));
   return f;
 }
 __device__ __forceinline__ float tex_filter(const LumaQuad& t, float a, float b) {
@@ -332,10 +334,11 @@ __device__ __forceinline__ void raw_descriptor_residual(const KfDev& kf, const C
 struct GradFootprint { int ix, iy; float tx, ty; };
 __device__ __forceinline__ GradFootprint grad_footprint(const CamConsts& c, f2 p) {
   GradFootprint g;
-  g.ix = f2i(fmaxf(0.f, p.x - 0.5f));
-  g.iy = f2i(fmaxf(0.f, p.y - 0.5f));
-  g.tx = fmaxf(0.f, fminf(1.f, p.x - 0.5f - (float)g.ix));
-  g.ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - (float)g.iy));
+  const float big = 3.0e38f;
+  g.ix = f2i(__builtin_amdgcn_fmed3f(p.x - 0.5f, 0.f, big));   // fmaxf(0, .)
+  g.iy = f2i(__builtin_amdgcn_fmed3f(p.y - 0.5f, 0.f, big));
+  g.tx = __builtin_amdgcn_fmed3f(p.x - 0.5f - (float)g.ix, 0.f, 1.f);
+  g.ty = __builtin_amdgcn_fmed3f(p.y - 0.5f - (float)g.iy, 0.f, 1.f);
   g.ix = min(g.ix, c.color_width - 1);
   g.iy = min(g.iy, c.color_height - 1);
   return g;
