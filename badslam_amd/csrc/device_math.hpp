@@ -407,6 +407,7 @@ struct Proj {
   f3 n_local;      // surfel normal rotated into the keyframe
   float depth;     // calibrated depth of the pixel
   int px, py;
+  float nx, ny;    // normalised image coordinates of the pixel centre (nx_of / ny_of), formed once per pair
   f2 pxy;
   uint32_t pixel_normal;  // raw u16 normal of the associated pixel
   uint32_t raw_depth;     // raw u16 depth of the associated pixel
@@ -469,7 +470,9 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   r->depth = __uint_as_float(rec.x);
   r->raw_depth = rec.y >> 16;
   r->n_local = rot34(T, gn);
-  const float stddev = depth_stddev(nx_of(c, (float)r->px), ny_of(c, (float)r->py), r->depth, r->n_local, c.inv_baseline_fx);
+  r->nx = nx_of(c, (float)r->px);
+  r->ny = ny_of(c, (float)r->py);
+  const float stddev = depth_stddev(r->nx, r->ny, r->depth, r->n_local, c.inv_baseline_fx);
   if (fabsf(r->local.z - r->depth) > kDepthTukey * stddev) return false;
   // reference: (1.0f / Norm(local)) * Dot(local, n_local) > 0  (:107-111).  1 / |local| is a positive,
   // finite, normal number for every |local| in [2^-126, 2^126] (and |local| >= local.z > 0 here), so the
@@ -484,12 +487,12 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
 
 // Depth residual and its pose Jacobian (BS/kernel_opt_pose.cu:45-94, BS/cost_function.cuh:56-88).
 __device__ __forceinline__ void depth_residual_and_jacobian(const CamConsts& c, const Proj& r, float* raw, float* J) {
-  const float inv_stddev = depth_inv_stddev(nx_of(c, (float)r.px), ny_of(c, (float)r.py), r.depth, r.n_local, c.baseline_fx);
+  const float inv_stddev = depth_inv_stddev(r.nx, r.ny, r.depth, r.n_local, c.baseline_fx);
   {
     // Past the association test nothing feeds an integer output any more: residual and Jacobian may use fused
     // multiply-adds (as the reference's nvcc build does by default); the predicate path stays unfused.
 #pragma clang fp contract(fast)
-    const f3 lu = mk3(r.depth * (c.fx_inv * r.px + c.cx_inv), r.depth * (c.fy_inv * r.py + c.cy_inv), r.depth);
+    const f3 lu = mk3(r.depth * r.nx, r.depth * r.ny, r.depth);
     const f3 dl = mk3(lu.x - r.local.x, lu.y - r.local.y, lu.z - r.local.z);
     *raw = inv_stddev * (r.n_local.x * dl.x + r.n_local.y * dl.y + r.n_local.z * dl.z);
     J[0] = inv_stddev * r.n_local.x;

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
-      const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, p.n_local, c.baseline_fx);
+      const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
       const float dj = -inv_stddev;
-      const f3 lu = unproject(c, p.px, p.py, p.depth);
+      const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
       const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
       const float w = depth_weight(raw);
       const float wj = w * dj;
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
       const f3 rn = p.n_local;
       if (kDepth) {
-        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
+        const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const float dj = -inv_stddev;
-        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
         const float w = depth_weight(raw);
         A0 += w * dj * dj;
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
     for (int r = 0; r < R; ++r) {
       Proj p;
       if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
-      const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, p.n_local, c.baseline_fx);
+      const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
       const float dj = -inv_stddev;
-      const f3 lu = unproject(c, p.px, p.py, p.depth);
+      const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
       const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
       const float w = depth_weight(raw);
       const float wj = w * dj;

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
-        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
-        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
+        const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
         const float weight = depth_weight(raw);
         if (P.optimize_geometry) {                               // :217-221
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
-        const float inv_stddev = depth_inv_stddev(nx_of(c, (float)p.px), ny_of(c, (float)p.py), p.depth, rn, c.baseline_fx);
-        const f3 lu = unproject(c, p.px, p.py, p.depth);
+        const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
+        const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
         const float weight = depth_weight(raw);
         float sum = 0;
