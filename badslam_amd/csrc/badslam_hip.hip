@@ -715,7 +715,10 @@ int bslam_optimize_geometry_iteration(
   if (!use_descriptor_residuals) {
     // at most one resident grid per launch (5 workgroups of 256 threads per CU at this kernel's register count), so that the
     // workgroups of a launch walk the keyframe table in near lockstep
-    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * 5) / 8u);   // slots per XCD and launch
+#ifndef BSLAM_GEOM_WG_PER_CU
+#define BSLAM_GEOM_WG_PER_CU 5
+#endif
+    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU) / 8u);   // slots per XCD and launch
     for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
       const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
       hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), dim3(8u * n), block, 0, stream, c, kfs, keyframe_count, sc, first, rows);
