@@ -419,6 +419,31 @@ int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float*
   return BSLAM_OK;
 }
 
+int bslam_assign_colors(
+    bslam_context* ctx, void* stream_, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* depth_params, int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size,
+    const bslam_buffer2d* surfels) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (surfels_size == 0) return BSLAM_OK;   // BS/kernel_assign_colors.cc:49-51
+  int rc = check_common(ctx, depth_camera, depth_params, surfels);
+  if (rc) return rc;
+  if (!color_camera) return fail(BSLAM_ERR_INVALID_ARGUMENT, "color_camera is null");
+  if (keyframe_count < 0 || (keyframe_count > 0 && !keyframes)) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad keyframe list");
+  if (surfels_size > (uint32_t)surfels->width) return fail(BSLAM_ERR_INVALID_ARGUMENT, "surfels_size %u exceeds the buffer width %d", surfels_size, surfels->width);
+  if (surfels->height <= BSLAM_SURFEL_COLOR) return fail(BSLAM_ERR_INVALID_ARGUMENT, "the surfel buffer has no colour row");
+  if (keyframe_count == 0) return BSLAM_OK;
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<KfDev> table;
+  if ((rc = build_kf_table(depth_camera, color_camera, true, keyframe_count, keyframes, &table))) return rc;
+  const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
+  if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
+  uint32_t* color_row = (uint32_t*)((uint8_t*)surfels->address + (size_t)BSLAM_SURFEL_COLOR * surfels->pitch);
+  hipLaunchKernelGGL(assign_colors_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count,
+                     surfel_rows_rw(surfels, nullptr, surfels_size), color_row);
+  BSLAM_HIP_TRY(hipGetLastError());
+  return BSLAM_OK;
+}
+
 int bslam_debug_decode_normals(bslam_context* ctx, void* stream_, float* out_xyz) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ctx || !out_xyz) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");

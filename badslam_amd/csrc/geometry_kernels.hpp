@@ -72,6 +72,51 @@ __global__ __launch_bounds__(256) void association_kernel(CamConsts c, const KfD
   out[i] = project_and_associate(c, kfs[0], gp, gn, &p) ? (uint32_t)(p.py * c.width + p.px) : 0xffffffffu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// AssignColorsCUDA (BS/kernel_assign_colors.cu:42-125): mean bilinear colour over the associated pixels of all
+// keyframes.  One launch, thread per surfel, sums in registers in keyframe order (the reference accumulates in
+// rows 8..12 with one launch per keyframe: same order of additions).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t texel_rgba(const KfDev& kf, const CamConsts& c, int ix, int iy) {   // clamp addressing
+  ix = min(max(ix, 0), c.color_width - 1);
+  iy = min(max(iy, 0), c.color_height - 1);
+  return gload((const uint32_t*)(kf.color + (size_t)iy * kf.color_pitch) + ix);
+}
+__device__ __forceinline__ uint8_t color_to_u8(float v) { return (uint8_t)min(255, max(0, f2i(v))); }   // cvt.rzi.u8.f32
+
+__global__ __launch_bounds__(256) void assign_colors_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s,
+                                                            uint32_t* __restrict__ color_row) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.size) return;
+  const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+  const f3 gn = unpack_normal(s.normal[i]);
+  float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kf_count; ++k) {
+    const KfDev kf = kfs[k];
+    Proj p;
+    if (!project_and_associate(c, kf, gp, gn, &p)) continue;
+    f2 cp;
+    if (!depth_to_color_pxy(c, p.pxy, &cp)) continue;
+    const TexFootprint f = tex_footprint(c, cp.x, cp.y);
+    const uint32_t t00 = texel_rgba(kf, c, f.i, f.j), t10 = texel_rgba(kf, c, f.i + 1, f.j);
+    const uint32_t t01 = texel_rgba(kf, c, f.i, f.j + 1), t11 = texel_rgba(kf, c, f.i + 1, f.j + 1);
+    const float w00 = (1.0f - f.a) * (1.0f - f.b), w10 = f.a * (1.0f - f.b), w01 = (1.0f - f.a) * f.b, w11 = f.a * f.b;
+    count += 1.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float v00 = (float)((t00 >> (8 * ch)) & 0xffu) * (1.0f / 255.0f), v10 = (float)((t10 >> (8 * ch)) & 0xffu) * (1.0f / 255.0f);
+      const float v01 = (float)((t01 >> (8 * ch)) & 0xffu) * (1.0f / 255.0f), v11 = (float)((t11 >> (8 * ch)) & 0xffu) * (1.0f / 255.0f);
+      sum[ch] += ((w00 * v00 + w10 * v10) + w01 * v01) + w11 * v11;
+    }
+  }
+  if (count > 0) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) packed |= (uint32_t)color_to_u8(255.f * sum[ch] / count + 0.5f) << (8 * ch);
+    color_row[i] = packed;
+  }
+}
+
 // bslam_debug_decode_normals: every u16 normal code through u16_to_image_space_normal
 __global__ __launch_bounds__(256) void decode_normals_kernel(float* __restrict__ out) {
   const uint32_t code = blockIdx.x * 256u + threadIdx.x;

@@ -49,6 +49,12 @@ def host_lib():
     L.bsh_upload_keyframe_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
     L.bsh_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.bsh_set_scheme_end_tasks.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_keyframe_is_deleted.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_delete_keyframe.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_merge_keyframes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.bsh_update_keyframe_covisibility.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_assign_colors.argtypes = [C.c_void_p, C.c_void_p]
+    L.bsh_export_point_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, f32p, u8p, f32p, C.POINTER(C.c_uint64)]
     L.bsh_create_surfels_for_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.bsh_set_allreduce.argtypes = [C.c_void_p, abi.ALLREDUCE_FN, C.c_void_p]
     L.bsh_estimate_frame_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p]
@@ -311,6 +317,34 @@ class DirectBA:
         buf = (C.c_int * 4096)()
         n = self.L.bsh_keyframe_covisibility(self._ba, kf_id, buf, 4096)
         return list(buf[:n])
+
+    # --- keyframe management and export (BS/direct_ba.h:95-126)
+    def keyframe_is_deleted(self, kf_id):
+        return bool(self.L.bsh_keyframe_is_deleted(self._ba, kf_id))
+
+    def DeleteKeyframe(self, kf_id):
+        self._check(self.L.bsh_delete_keyframe(self._ba, kf_id))
+
+    def MergeKeyframes(self, approx_merge_count):
+        """Returns the ids of the deleted keyframes."""
+        ids = (C.c_int * 4096)()
+        n = C.c_int()
+        self._check(self.L.bsh_merge_keyframes(self._ba, self.stream, approx_merge_count, ids, 4096, C.byref(n)))
+        return list(ids[:n.value])
+
+    def UpdateKeyframeCoVisibility(self, kf_id):
+        self._check(self.L.bsh_update_keyframe_covisibility(self._ba, kf_id))
+
+    def AssignColors(self):
+        self._check(self.L.bsh_assign_colors(self._ba, self.stream))
+
+    def ExportToPointCloud(self):
+        """(positions (n, 3) f32, colors (n, 3) u8, normals (n, 3) f32) of the valid surfels."""
+        cap = max(1, self.surfels_size())
+        pos, col, nrm = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.uint8), np.zeros((cap, 3), np.float32)
+        n = C.c_uint64()
+        self._check(self.L.bsh_export_point_cloud(self._ba, self.stream, cap, _f(pos), col.ctypes.data_as(C.POINTER(C.c_uint8)), _f(nrm), C.byref(n)))
+        return pos[:n.value], col[:n.value], nrm[:n.value]
 
     def upload_keyframe_depth(self, kf_id, depth):
         d = np.ascontiguousarray(depth, np.uint16)

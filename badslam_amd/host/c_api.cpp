@@ -123,6 +123,36 @@ int bsh_get_keyframe_images(void* ba, void* stream, int id, uint16_t* depth, uin
     min_max[1] = kf->max_depth();
   });
 }
+// Keyframe management and export (BS/direct_ba.h:95-116, 123-126)
+int bsh_keyframe_is_deleted(void* ba, int id) { return static_cast<DirectBA*>(ba)->keyframes().at(id) ? 0 : 1; }
+int bsh_delete_keyframe(void* ba, int id) { BSH_TRY(static_cast<DirectBA*>(ba)->DeleteKeyframe(id)); }
+int bsh_merge_keyframes(void* ba, void* stream, uint64_t approx_merge_count, int* deleted_ids, int capacity, int* deleted_count) {
+  BSH_TRY({
+    const std::vector<int> ids = static_cast<DirectBA*>(ba)->MergeKeyframes(static_cast<hipStream_t>(stream), static_cast<size_t>(approx_merge_count));
+    for (size_t i = 0; i < ids.size() && static_cast<int>(i) < capacity; ++i) deleted_ids[i] = ids[i];
+    *deleted_count = static_cast<int>(ids.size());
+  });
+}
+int bsh_update_keyframe_covisibility(void* ba, int id) {
+  BSH_TRY({
+    DirectBA* b = static_cast<DirectBA*>(ba);
+    if (!b->keyframes().at(id)) throw std::invalid_argument("keyframe was deleted");
+    b->UpdateKeyframeCoVisibility(b->keyframes().at(id));
+  });
+}
+int bsh_assign_colors(void* ba, void* stream) { BSH_TRY(static_cast<DirectBA*>(ba)->AssignColors(static_cast<hipStream_t>(stream))); }
+// Fills up to `capacity` points; *count receives the number of valid surfels.
+int bsh_export_point_cloud(void* ba, void* stream, uint64_t capacity, float* positions, uint8_t* colors, float* normals, uint64_t* count) {
+  BSH_TRY({
+    DirectBA::PointCloud cloud;
+    static_cast<DirectBA*>(ba)->ExportToPointCloud(static_cast<hipStream_t>(stream), &cloud);
+    const size_t n = std::min<size_t>(cloud.size(), capacity);
+    if (positions) std::memcpy(positions, cloud.positions.data(), n * 3 * sizeof(float));
+    if (colors) std::memcpy(colors, cloud.colors.data(), n * 3);
+    if (normals) std::memcpy(normals, cloud.normals.data(), n * 3 * sizeof(float));
+    *count = cloud.size();
+  });
+}
 int bsh_set_scheme_end_tasks(void* ba, int enable) { BSH_TRY(static_cast<DirectBA*>(ba)->SetSchemeEndTasks(enable != 0)); }
 int bsh_create_surfels_for_keyframe(void* ba, void* stream, int filter_new_surfels, int keyframe_id) {
   BSH_TRY({

@@ -278,6 +278,138 @@ void DirectBA::DetermineCovisibleActiveKeyframes() {
   }
 }
 
+// BS/direct_ba.cc:207-229
+void DirectBA::DeleteKeyframe(int keyframe_index) {
+  if (keyframe_index < 0 || keyframe_index >= static_cast<int>(keyframes_.size()) || !keyframes_[keyframe_index])
+    throw std::invalid_argument("DeleteKeyframe: no keyframe with index " + std::to_string(keyframe_index));
+  const std::shared_ptr<Keyframe> frame_to_delete = keyframes_[keyframe_index];
+  for (int covis_index : frame_to_delete->co_visibility_list()) {
+    Keyframe* covis_frame = keyframes_[covis_index].get();
+    if (!covis_frame) continue;
+    auto& list = covis_frame->co_visibility_list();
+    for (size_t i = 0; i < list.size(); ++i) {
+      if (list[i] == keyframe_index) { list.erase(list.begin() + i); break; }
+    }
+  }
+  keyframes_[keyframe_index].reset();
+  InvalidateKeyframeCache();   // the derived per-keyframe images are indexed by table position
+}
+
+// BS/direct_ba.cc:710-737
+void DirectBA::UpdateKeyframeCoVisibility(const std::shared_ptr<Keyframe>& keyframe) {
+  for (int covis_index : keyframe->co_visibility_list()) {
+    Keyframe* covis_frame = keyframes_[covis_index].get();
+    if (!covis_frame) continue;
+    auto& list = covis_frame->co_visibility_list();
+    for (size_t i = 0; i < list.size(); ++i) {
+      if (list[i] == keyframe->id()) { list.erase(list.begin() + i); break; }
+    }
+  }
+  keyframe->co_visibility_list().clear();
+  CameraFrustum frustum(depth_camera_, keyframe->min_depth(), keyframe->max_depth(), keyframe->global_T_frame());
+  for (const auto& other : keyframes_) {
+    if (!other) continue;
+    // Quirk kept: the reference does not exclude the keyframe itself (:724-735), so it intersects its own frustum and
+    // enters its own list twice (unlike DetermineNewKeyframeCoVisibility, which runs before the keyframe is stored).
+    CameraFrustum other_frustum(depth_camera_, other->min_depth(), other->max_depth(), other->global_T_frame());
+    if (frustum.Intersects(&other_frustum)) {
+      keyframe->co_visibility_list().push_back(other->id());
+      other->co_visibility_list().push_back(keyframe->id());
+    }
+  }
+}
+
+// BS/direct_ba.cc:251-338
+std::vector<int> DirectBA::MergeKeyframes(hipStream_t /*stream*/, size_t approx_merge_count) {
+  constexpr float kPiHalf = 1.57079632679489661923f;
+  constexpr float kMaxAngleDifference = 0.5f * kPiHalf;
+  constexpr float kMaxEuclideanDistance = 0.3f;
+  std::vector<int> deleted;
+  if (keyframes_.size() <= 1) return deleted;
+  struct MergeDistance { float distance; int prev_id, id, next_id; };
+  std::vector<MergeDistance> distances;
+  float prev_half_distance = 0;
+  int prev_keyframe_id = 0;
+  const auto z_axis = [](const SE3f& T, float* z) { const bslam_mat3x4 m = T.Matrix3x4(); z[0] = m.m[2]; z[1] = m.m[6]; z[2] = m.m[10]; };
+  const auto translation = [](const SE3f& T, float* t) { const bslam_mat3x4 m = T.Matrix3x4(); t[0] = m.m[3]; t[1] = m.m[7]; t[2] = m.m[11]; };
+  for (size_t keyframe_id = 0; keyframe_id + 1 < keyframes_.size(); ++keyframe_id) {
+    const auto& keyframe = keyframes_[keyframe_id];
+    if (!keyframe) continue;
+    const Keyframe* next_keyframe = nullptr;
+    for (size_t next_id = keyframe_id + 1; next_id < keyframes_.size(); ++next_id) {
+      if (keyframes_[next_id]) { next_keyframe = keyframes_[next_id].get(); break; }
+    }
+    if (!next_keyframe) break;
+    float za[3], zb[3], ta[3], tb[3];
+    z_axis(keyframe->global_T_frame(), za);
+    z_axis(next_keyframe->global_T_frame(), zb);
+    // (clamped: two equal rotations can give a dot product of 1 + 1 ulp, for which acosf returns NaN -- the
+    // reference has no guard there)
+    const float angle_difference = std::acos(std::min(1.f, std::max(-1.f, za[0] * zb[0] + za[1] * zb[1] + za[2] * zb[2])));
+    if (angle_difference > kMaxAngleDifference) continue;
+    translation(keyframe->global_T_frame(), ta);
+    translation(next_keyframe->global_T_frame(), tb);
+    const float dx = ta[0] - tb[0], dy = ta[1] - tb[1], dz = ta[2] - tb[2];
+    const float euclidean_distance = std::sqrt(dx * dx + dy * dy + dz * dz);
+    if (euclidean_distance > kMaxEuclideanDistance) continue;
+    // 90 degrees count like half a metre (:296-297)
+    const float next_half_distance = euclidean_distance + (0.5f / kPiHalf) * angle_difference;
+    if (keyframe_id > 0) distances.push_back({prev_half_distance + next_half_distance, prev_keyframe_id, static_cast<int>(keyframe_id), next_keyframe->id()});
+    prev_half_distance = next_half_distance;
+    prev_keyframe_id = static_cast<int>(keyframe_id);
+  }
+  const size_t sorted = std::min(approx_merge_count, distances.size());
+  std::partial_sort(distances.begin(), distances.begin() + sorted, distances.end(),
+                    [](const MergeDistance& a, const MergeDistance& b) { return a.distance < b.distance; });
+  for (size_t i = 0; i < sorted; ++i) {
+    const MergeDistance& merge = distances[i];
+    if (!keyframes_[merge.prev_id] || !keyframes_[merge.id] || !keyframes_[merge.next_id]) continue;   // a neighbour went in an earlier merge (:322-327)
+    DeleteKeyframe(merge.id);   // the reference "merges" by deleting, too (:329-332)
+    deleted.push_back(merge.id);
+  }
+  return deleted;
+}
+
+// BS/direct_ba.cc:456-459
+void DirectBA::AssignColors(hipStream_t stream) {
+  if (surfels_size_ == 0) return;
+  const std::vector<bslam_keyframe_view> views = KeyframeViews();
+  const bslam_camera4f color_cam = color_camera_.pod(), depth_cam = depth_camera_.pod();
+  const bslam_depth_params dp = depth_params();
+  const bslam_buffer2d surfels = surfels_->ToPod();
+  Check(bslam_assign_colors(ctx_, stream, &color_cam, &depth_cam, &dp, static_cast<int>(views.size()), views.data(), surfels_size_, &surfels),
+        "bslam_assign_colors");
+}
+
+// BS/direct_ba.cc:461-546
+void DirectBA::ExportToPointCloud(hipStream_t stream, PointCloud* cloud) const {
+  cloud->positions.clear();
+  cloud->colors.clear();
+  cloud->normals.clear();
+  if (surfels_size_ == 0) return;
+  const size_t n = surfels_size_;
+  std::vector<float> rows(6 * n);   // rows 0..5: x, y, z, normal, radius^2, colour
+  GetSurfels(stream, rows.data(), n * sizeof(float), 6);
+  const float* x = rows.data();
+  const float* y = x + n;
+  const float* z = y + n;
+  const u32* normal = reinterpret_cast<const u32*>(z + n);
+  const u32* color = reinterpret_cast<const u32*>(rows.data() + 5 * n);
+  const auto ten_bit = [](u32 v) {   // TenBitSignedToFloat, BS/util_nvcc_only.cuh:74-78
+    const int16_t s = static_cast<int16_t>((v & 0x03ffu) << 6) >> 6;
+    return static_cast<float>(s) * (1.0f / 511);
+  };
+  cloud->positions.reserve(3 * surfel_count_);
+  for (size_t i = 0; i < n; ++i) {
+    if (std::isnan(x[i])) continue;   // deleted surfels carry NaN in x (:469-476)
+    cloud->positions.insert(cloud->positions.end(), {x[i], y[i], z[i]});
+    cloud->colors.insert(cloud->colors.end(), {static_cast<u8>(color[i] & 0xff), static_cast<u8>((color[i] >> 8) & 0xff), static_cast<u8>((color[i] >> 16) & 0xff)});
+    const float nx = ten_bit(normal[i]), ny = ten_bit(normal[i] >> 10), nz = ten_bit(normal[i] >> 20);
+    const float factor = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
+    cloud->normals.insert(cloud->normals.end(), {factor * nx, factor * ny, factor * nz});
+  }
+}
+
 std::vector<bslam_keyframe_view> DirectBA::KeyframeViews() const {
   // Deleted keyframes (null entries) are skipped by every kernel wrapper of the reference
   // (BS/kernel_opt_geometry.cc:115); here they are simply left out of the table.

@@ -176,7 +176,25 @@ class DirectBA {
                         int pcg_max_inner_iterations = 30, int pcg_max_keyframes = 2500,
                         std::function<bool(int)> progress_function = nullptr);
 
-  // Scene state in / out.  Surfel creation is a "next" row: callers upload surfels made elsewhere.
+  // Keyframe management of the outer seam (BS/direct_ba.h:95-116).  The reference's LoopDetector* parameters are
+  // dropped: loop detection stays with the caller, which removes the image from its own detector.
+  void DeleteKeyframe(int keyframe_index);                                    // BS/direct_ba.cc:207-229
+  // Deletes up to approx_merge_count keyframes that are close to both neighbours on the trajectory (never keyframe 0);
+  // returns the deleted ids in the order of deletion.                         // BS/direct_ba.cc:251-338
+  std::vector<int> MergeKeyframes(hipStream_t stream, size_t approx_merge_count);
+  void UpdateKeyframeCoVisibility(const std::shared_ptr<Keyframe>& keyframe);  // BS/direct_ba.cc:710-737
+  void AssignColors(hipStream_t stream);                                       // BS/direct_ba.cc:456-459
+  // ExportToPointCloud (BS/direct_ba.cc:461-546): the valid (non-NaN) surfels as host arrays; normals are
+  // re-normalised 10-bit normals as in the reference.
+  struct PointCloud {
+    std::vector<float> positions;   // 3 per point
+    std::vector<u8> colors;         // 3 per point (r, g, b)
+    std::vector<float> normals;     // 3 per point
+    size_t size() const { return positions.size() / 3; }
+  };
+  void ExportToPointCloud(hipStream_t stream, PointCloud* cloud) const;
+
+  // Scene state in / out.
   void SetSurfels(hipStream_t stream, const float* host_rows, size_t host_pitch_bytes, u32 count);
   void GetSurfels(hipStream_t stream, float* host_rows, size_t host_pitch_bytes, int rows) const;
   void GetActiveSurfels(hipStream_t stream, u8* host) const;

@@ -310,6 +310,16 @@ int bslam_debug_association(
     uint32_t surfels_size, const bslam_buffer2d* surfels,
     uint32_t* out_pixel);
 
+/* Replaces AssignColorsCUDA (BS/kernels.h:301-308, BS/kernel_assign_colors.cc:40-80, .cu:42-125): every surfel's
+ * colour row becomes the mean of the bilinearly filtered uchar4 colours of the pixels it is associated with over ALL
+ * listed keyframes (activation is ignored, as in the reference); surfels without an observation keep their colour.
+ * The reference's scratch rows 8..12 are not written (sums live in registers). */
+int bslam_assign_colors(
+    bslam_context* ctx, void* stream,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels);
+
 /* Decodes all 65536 u16 image-space normal codes (BS/util.cuh:120-130) with the kernels' own routine into
  * HOST out_xyz[65536 * 3]; lets the tests compare the device's correctly rounded z = -sqrt(1 - x^2 - y^2) with the
  * CPU's bit for bit over the whole domain. */

@@ -472,6 +472,71 @@ void bso_update_surfel_activation(
 
 #define ACC(s, row, i) BSO_AT(float, s, BSLAM_SURFEL_ACCUM0 + (row), i)
 
+/* ---- AssignColorsCUDA (BS/kernel_assign_colors.cc:40-80, BS/kernel_assign_colors.cu:42-125) ---- */
+static void bso_texel_rgba(const bslam_buffer2d* color, int ix, int iy, float out[4]) {   /* clamp addressing, u8 -> [0, 1] */
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix > color->width - 1) ix = color->width - 1;
+  if (iy > color->height - 1) iy = color->height - 1;
+  const uint8_t* px = (const uint8_t*)color->address + (size_t)iy * color->pitch + 4 * (size_t)ix;
+  for (int ch = 0; ch < 4; ++ch) out[ch] = px[ch] * (1.0f / 255.0f);
+}
+/* tex2D<float4> with the texture model of bso_tex_w (bso_math.h) */
+static void bso_tex_rgba(const bslam_buffer2d* color, float x, float y, int mode, float out[4]) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (mode == BSLAM_TEX_FIXED_POINT_1_8) {
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  }
+  const int i = (int)fminf(fmaxf(fx, -2.0f), (float)color->width);
+  const int j = (int)fminf(fmaxf(fy, -2.0f), (float)color->height);
+  float t00[4], t10[4], t01[4], t11[4];
+  bso_texel_rgba(color, i, j, t00);
+  bso_texel_rgba(color, i + 1, j, t10);
+  bso_texel_rgba(color, i, j + 1, t01);
+  bso_texel_rgba(color, i + 1, j + 1, t11);
+  const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  for (int ch = 0; ch < 4; ++ch) out[ch] = ((w00 * t00[ch] + w10 * t10[ch]) + w01 * t01[ch]) + w11 * t11[ch];
+}
+static uint8_t bso_float_to_u8(float v) {   /* cvt.rzi.u8.f32: truncate, saturate */
+  int i = bso_f2i(v);
+  if (i < 0) i = 0;
+  if (i > 255) i = 255;
+  return (uint8_t)i;
+}
+
+void bso_assign_colors(
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes, int tex_mode,
+    uint32_t surfels_size, const bslam_buffer2d* surfels) {
+  if (surfels_size == 0) return;                                   /* BS/kernel_assign_colors.cc:49-51 */
+  bso_unprojector unproj = bso_make_unprojector(depth_camera);
+  bso_depth_to_color d2c = bso_make_depth_to_color(depth_camera, color_camera);
+  for (uint32_t i = 0; i < surfels_size; ++i)                      /* ResetSurfelForColorAssignmentKernel .cu:42-55 */
+    for (int r = 0; r < 5; ++r) ACC(surfels, r, i) = 0;
+  for (int k = 0; k < keyframe_count; ++k) {                       /* every listed keyframe, whatever its activation (.cc:60-73) */
+    const bslam_keyframe_view* kf = &keyframes[k];
+    for (uint32_t i = 0; i < surfels_size; ++i) {                  /* AccumulateColorObservationsCUDAKernel .cu:74-93 */
+      bso_projection r;
+      if (!bso_surfel_projects_to_associated_pixel(i, surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r)) continue;
+      bso_f2 color_pxy;
+      if (!bso_depth_to_color_pxy(r.pxy, &d2c, &color_pxy)) continue;
+      float c[4];
+      bso_tex_rgba(&kf->color, color_pxy.x, color_pxy.y, tex_mode, c);
+      ACC(surfels, 0, i) += 1.f;
+      for (int ch = 0; ch < 4; ++ch) ACC(surfels, 1 + ch, i) += c[ch];
+    }
+  }
+  for (uint32_t i = 0; i < surfels_size; ++i) {                    /* AssignColorsCUDAKernel .cu:111-125 */
+    const float n = ACC(surfels, 0, i);
+    if (!(n > 0)) continue;
+    uint8_t* out = (uint8_t*)&BSO_AT(float, surfels, BSLAM_SURFEL_COLOR, i);
+    for (int ch = 0; ch < 4; ++ch) out[ch] = bso_float_to_u8(255.f * ACC(surfels, 1 + ch, i) / n + 0.5f);
+  }
+}
+
 void bso_update_surfel_normals(
     const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
     int keyframe_count, const bslam_keyframe_view* keyframes,

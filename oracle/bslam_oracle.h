@@ -82,6 +82,12 @@ void bso_estimate_frame_pose(
     int tex_mode, int max_iterations, bslam_se3f* out_global_T_frame, int* iterations_done, int* converged);
 
 /* UpdateSurfelActivationCUDA (BS/kernel_surfel_activation.cc:39-67). */
+/* AssignColorsCUDA (BS/kernels.h:301-308).  Writes the scratch rows 8..12 like the reference. */
+void bso_assign_colors(
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes, int tex_mode,
+    uint32_t surfels_size, const bslam_buffer2d* surfels);
+
 void bso_update_surfel_activation(
     const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
     int keyframe_count, const bslam_keyframe_view* keyframes,

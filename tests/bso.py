@@ -55,6 +55,7 @@ def lib():
         "bso_estimate_frame_pose": (None, [
             C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, P(abi.SE3f), C.c_uint32, _BUF,
             C.c_int, C.c_int, P(abi.SE3f), P(C.c_int), P(C.c_int)]),
+        "bso_assign_colors": (None, [_CAM, _CAM, _DP, C.c_int, _KFS, C.c_int, C.c_uint32, _BUF]),
         "bso_update_surfel_activation": (None, [_CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
         "bso_update_surfel_normals": (None, [_CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF]),
         "bso_optimize_geometry_iteration": (None, [
@@ -370,6 +371,11 @@ class HostScene:
         dp, sb, ab, kfs = self.depth_params(), self.surfel_buf(), self.active_buf(), self.keyframe_views()
         lib().bso_update_surfel_activation(C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs,
                                            self.surfels_size, C.byref(sb), C.byref(ab))
+
+    def assign_colors(self):
+        dp, sb, kfs = self.depth_params(), self.surfel_buf(), self.keyframe_views()
+        lib().bso_assign_colors(C.byref(self.color_camera), C.byref(self.depth_camera), C.byref(dp), len(self.keyframes), kfs,
+                                self.tex_mode, self.surfels_size, C.byref(sb))
 
     def update_normals(self):
         dp, sb, ab, kfs = self.depth_params(), self.surfel_buf(), self.active_buf(), self.keyframe_views()

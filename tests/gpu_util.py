@@ -133,6 +133,14 @@ class Hip:
         self.torch.cuda.synchronize()
 
 
+    def assign_colors(self):
+        dp, sb = self._common()
+        kfs = self.d.keyframe_views()
+        badslam_amd.check(self.L.bslam_assign_colors(
+            self.ctx.handle, stream_ptr(), C.byref(self.h.color_camera), C.byref(self.h.depth_camera), C.byref(dp),
+            len(self.h.keyframes), kfs, self.d.surfels_size, C.byref(sb)))
+        self.torch.cuda.synchronize()
+
     # --- surfel lifecycle
     def create_surfels_for_keyframe(self, kf_index, filter_new_surfels, min_observation_count, covis_indices):
         dp, sb = self._common()

@@ -327,3 +327,86 @@ def test_save_and_load_state_through_direct_ba(oracle, tmp_path):
     assert np.array_equal(other.GetSurfels(8).view(np.uint32), ba.GetSurfels(8).view(np.uint32))
     for k in range(3):
         assert np.array_equal(bso.se3_to_np(other.keyframe_pose(k)), bso.se3_to_np(ba.keyframe_pose(k)))
+
+
+def test_keyframe_management_colors_and_export(oracle):
+    """The rest of DirectBA's outer seam (BS/direct_ba.h:95-126): DeleteKeyframe, UpdateKeyframeCoVisibility,
+    MergeKeyframes, AssignColors, ExportToPointCloud -- and BundleAdjustment with a deleted keyframe in the list
+    (null entries are skipped, BS/kernel_opt_geometry.cc:115)."""
+    scene = scenes.synthetic_scene(6, seed=9, use_depth_residuals=True, use_descriptor_residuals=True)
+    K = len(scene.keyframes)
+    ba = make_ba(scene)
+    # co-visibility from AddKeyframe is symmetric and free of self entries (BS/direct_ba.cc:231-249)
+    lists = [ba.keyframe_covisibility(k) for k in range(K)]
+    for k in range(K):
+        assert k not in lists[k] and all(k in lists[j] for j in lists[k])
+    assert all(len(l) > 0 for l in lists)
+
+    # AssignColors through the host class == the oracle on the same scene, byte for byte
+    ba.AssignColors()
+    scene.assign_colors()
+    n = scene.surfels_size
+    assert np.array_equal(ba.GetSurfels(8)[5, :n].view(np.uint32), scene.surfels[5, :n].view(np.uint32))
+
+    # DeleteKeyframe: gone from every list; everything that walks the keyframes keeps working
+    ba.DeleteKeyframe(2)
+    assert ba.keyframe_is_deleted(2) and not ba.keyframe_is_deleted(1)
+    assert all(2 not in ba.keyframe_covisibility(k) for k in range(K) if k != 2)
+    with pytest.raises(Exception):
+        ba.DeleteKeyframe(2)
+    before = np.array([dba_pose7(ba, k) for k in range(K) if k != 2])
+    ba.BundleAdjustment(False, False, False, True, True, 2, 4, False, 0, K - 1, True)
+    after = np.array([dba_pose7(ba, k) for k in range(K) if k != 2])
+    surfels = ba.GetSurfels(8)
+    assert np.isfinite(after).all() and np.abs(after - before).max() < 1e-2
+    assert np.isfinite(surfels[:3, :ba.surfels_size()]).all()
+    ba.AssignColors()     # the table without keyframe 2
+
+    # UpdateKeyframeCoVisibility after a pose change: a keyframe moved 100 m away sees nobody any more -- except
+    # itself, twice (the reference does not skip the keyframe itself, BS/direct_ba.cc:724-735)
+    T = ba.keyframe_pose(3)
+    T.t[0] += 100.0
+    ba.set_keyframe_pose(3, T)
+    ba.UpdateKeyframeCoVisibility(3)
+    assert ba.keyframe_covisibility(3) == [3, 3]
+    assert all(3 not in ba.keyframe_covisibility(k) for k in range(K) if k not in (2, 3))
+
+    # ExportToPointCloud: the non-NaN surfels with colours and re-normalised normals
+    pos, col, nrm = ba.ExportToPointCloud()
+    rows = ba.GetSurfels(8)[:, :ba.surfels_size()]
+    valid = ~np.isnan(rows[0])
+    assert len(pos) == valid.sum() == len(col) == len(nrm)
+    assert np.array_equal(pos, rows[:3, valid].T)
+    packed = rows[5, valid].view(np.uint32)
+    assert np.array_equal(col, np.stack([packed & 0xff, (packed >> 8) & 0xff, (packed >> 16) & 0xff], axis=1).astype(np.uint8))
+    assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-6
+
+
+def dba_pose7(ba, k):
+    from badslam_amd import direct_ba as dba
+    return dba.pose7(ba.keyframe_pose(k))
+
+
+def test_merge_keyframes_deletes_the_closest_inner_keyframes(oracle):
+    """MergeKeyframes (BS/direct_ba.cc:251-338): candidates are keyframes within 0.3 m and 45 degrees of the next one,
+    ranked by distance to previous + next; keyframe 0 is never deleted, a keyframe whose neighbour went in the same call
+    is skipped."""
+    scene = scenes.synthetic_scene(7, seed=10, use_depth_residuals=True, use_descriptor_residuals=False)
+    ba = make_ba(scene)
+    base = ba.keyframe_pose(0)
+    # keyframes on a line: gaps 0.10, 0.02, 0.03, 0.25, 0.05, 0.50 m (the last gap is beyond the 0.3 m limit)
+    x = np.cumsum([0.0, 0.10, 0.02, 0.03, 0.25, 0.05, 0.50])
+    for k in range(7):
+        T = ba.keyframe_pose(0)
+        T.t[0] = base.t[0] + float(x[k])
+        ba.set_keyframe_pose(k, T)
+    # candidates (id: prev gap + next gap): 1: 0.12, 2: 0.05, 3: 0.28, 4: 0.30; 5 has no valid next gap (0.5 m), 6 is last
+    deleted = ba.MergeKeyframes(2)
+    # sorted: 2 (0.05), 1 (0.12): 2 goes first, then 1 is skipped because its next keyframe (2) is gone
+    assert deleted == [2]
+    assert ba.keyframe_is_deleted(2) and not ba.keyframe_is_deleted(0)
+    deleted = ba.MergeKeyframes(10)
+    # now 1: 0.10 + 0.05 = 0.15, 3: 0.05 + 0.25 = 0.30, 4: 0.25 + 0.05 = 0.30 -> 1 goes, then 3 (prev 1 gone -> skipped), 4 (prev 3 alive, next 5 alive) goes
+    assert 0 not in deleted and 6 not in deleted and 1 in deleted
+    assert all(ba.keyframe_is_deleted(k) for k in deleted)
+    assert ba.MergeKeyframes(0) == []

@@ -331,3 +331,33 @@ def test_normal_decode_is_correctly_rounded_over_the_whole_domain():
     assert np.array_equal(out[:, 1].view(np.uint32), y.view(np.uint32))
     assert np.array_equal(out[:, 2].view(np.uint32), z.astype(np.float32).view(np.uint32))
     assert (z2 > 0).sum() > 40000 and (z2 <= 0).sum() > 10000      # both branches of the clamp are exercised
+
+
+@pytest.mark.parametrize("tex_mode", ["fixed", "float"])
+def test_assign_colors_bit_exact(oracle, tex_mode):
+    """AssignColorsCUDA (BS/kernel_assign_colors.cu): the uchar4 colour row after one launch over all keyframes equals
+    the oracle's per-keyframe accumulation byte for byte; surfels nobody observes keep their colour."""
+    from badslam_amd import abi
+    from tests import gpu_util
+    mode = abi.TEX_FIXED_POINT_1_8 if tex_mode == "fixed" else abi.TEX_EXACT_FLOAT
+    scene = scenes.synthetic_scene(4, seed=5, use_depth_residuals=True, use_descriptor_residuals=True, tex_mode=mode)
+    n = scene.surfels_size
+    # a few surfels far away from everything: no observation, colour must survive
+    scene.surfels[0:3, n - 50:n] += 100.0
+    sentinel = np.uint32(0x11223344)
+    scene.surfels[5, :n] = np.full(n, sentinel, np.uint32).view(np.float32)
+    # the keyframe colour images carry luma in all channels in the generator; make the channels differ
+    rng = np.random.default_rng(0)
+    for kf in scene.keyframes:
+        kf.color[..., 0] = (kf.color[..., 3].astype(np.int32) * 3 // 4).astype(np.uint8)
+        kf.color[..., 1] = 255 - kf.color[..., 3]
+        kf.color[..., 2] = rng.integers(0, 256, kf.color.shape[:2], dtype=np.uint8)
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))     # the texture mode travels with the host scene
+    hip.assign_colors()
+    got = hip.d.surfels_np()[5, :n].view(np.uint32)
+    scene.assign_colors()
+    want = scene.surfels[5, :n].view(np.uint32)
+    assert np.array_equal(got, want)
+    changed = want != sentinel
+    assert changed.sum() > 0.9 * (n - 50) and not changed[n - 50:].any()
+    assert len(np.unique(want[changed] & 0xff)) > 50 and len(np.unique((want[changed] >> 16) & 0xff)) > 50
