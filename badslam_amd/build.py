@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
     if force or needs_host_build():
-        cmd = ["g++"] + [os.path.join(HOST, f) for f in ("direct_ba.cpp", "io.cpp", "pairwise_frame_tracking.cpp", "c_api.cpp")] + HOST_FLAGS + ["-lz", "-o", HOST_SO]
+        cmd = ["g++"] + [os.path.join(HOST, f) for f in ("direct_ba.cpp", "io.cpp", "pairwise_frame_tracking.cpp", "bad_slam.cpp", "c_api.cpp")] + HOST_FLAGS + ["-lz", "-o", HOST_SO]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

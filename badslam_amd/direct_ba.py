@@ -313,6 +313,10 @@ class DirectBA:
     def set_keyframe_activation(self, kf_id, act):
         self._check(self.L.bsh_set_keyframe_activation(self._ba, kf_id, act))
 
+    def keyframe_count(self):
+        """keyframes().size(): includes deleted (null) entries."""
+        return self.L.bsh_keyframe_count(self._ba)
+
     def keyframe_covisibility(self, kf_id):
         buf = (C.c_int * 4096)()
         n = self.L.bsh_keyframe_covisibility(self._ba, kf_id, buf, 4096)

@@ -5,6 +5,7 @@
 #include <memory>
 #include <string>
 
+#include "bad_slam.hpp"
 #include "direct_ba.hpp"
 #include "io.hpp"
 #include "pairwise_frame_tracking.hpp"
@@ -427,6 +428,60 @@ int bsh_track_keyframe_pair(void* ba_, void* stream, int tracked_id, int base_id
                        base->normals_buffer(), base->color_buffer(), test_different_initial_estimates != 0, pose_from7(init1_pose7),
                        pose_from7(init2_pose7 ? init2_pose7 : init1_pose7), &out, iterations);
     pose_to7(out, out_pose7);
+  });
+}
+
+// ---- BadSlam front end (host/bad_slam.hpp) ----
+// cfg: [keyframe_interval, max_num_ba_iterations_per_keyframe, num_scales, max_surfel_count, sparse_surfel_cell_size, use_motion_model,
+//       use_geometric_residuals, use_photometric_residuals, do_surfel_updates, use_pcg, optimize_intrinsics, disable_deactivation, start_frame]
+// fcfg: [raw_to_float_depth, max_depth, baseline_fx]
+void* bsh_slam_create(const int* cfg, const float* fcfg, int color_width, int color_height, const float* color_params, int depth_width, int depth_height,
+                      const float* depth_params, int device) {
+  try {
+    BadSlamConfigV1 c;
+    c.keyframe_interval = cfg[0]; c.max_num_ba_iterations_per_keyframe = cfg[1]; c.num_scales = cfg[2]; c.max_surfel_count = cfg[3];
+    c.sparse_surfel_cell_size = cfg[4]; c.use_motion_model = cfg[5] != 0; c.use_geometric_residuals = cfg[6] != 0;
+    c.use_photometric_residuals = cfg[7] != 0; c.do_surfel_updates = cfg[8] != 0; c.use_pcg = cfg[9] != 0; c.optimize_intrinsics = cfg[10] != 0;
+    c.disable_deactivation = cfg[11] != 0; c.start_frame = cfg[12];
+    c.raw_to_float_depth = fcfg[0]; c.max_depth = fcfg[1]; c.baseline_fx = fcfg[2];
+    return new BadSlam(c, PinholeCamera4f(color_width, color_height, color_params), PinholeCamera4f(depth_width, depth_height, depth_params), device);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void bsh_slam_destroy(void* slam) { delete static_cast<BadSlam*>(slam); }
+void* bsh_slam_direct_ba(void* slam) { return &static_cast<BadSlam*>(slam)->direct_ba(); }
+int bsh_slam_process_frame(void* slam, int frame_index, const uint16_t* depth, const uint8_t* rgb, int force_keyframe) {
+  BSH_TRY(static_cast<BadSlam*>(slam)->ProcessFrame(frame_index, depth, rgb, force_keyframe != 0));
+}
+int bsh_slam_run_bundle_adjustment(void* slam, int frame_index, int optimize_depth_intrinsics, int optimize_color_intrinsics, int optimize_poses,
+                                   int optimize_geometry, int min_iterations, int max_iterations, int window_start, int window_end,
+                                   int increase_ba_iteration_count, int* iterations_done, int* converged) {
+  BSH_TRY({
+    bool conv = false;
+    int done = 0;
+    static_cast<BadSlam*>(slam)->RunBundleAdjustment(static_cast<uint32_t>(frame_index), optimize_depth_intrinsics != 0, optimize_color_intrinsics != 0,
+                                                     optimize_poses != 0, optimize_geometry != 0, min_iterations, max_iterations, window_start, window_end,
+                                                     increase_ba_iteration_count != 0, &done, &conv);
+    if (iterations_done) *iterations_done = done;
+    if (converged) *converged = conv ? 1 : 0;
+  });
+}
+int bsh_slam_frame_count(void* slam) { return static_cast<int>(static_cast<BadSlam*>(slam)->frame_poses().size()); }
+int bsh_slam_get_frame_poses(void* slam, float* poses7, int capacity) {
+  BSH_TRY({
+    const auto& poses = static_cast<BadSlam*>(slam)->frame_poses();
+    for (size_t i = 0; i < poses.size() && static_cast<int>(i) < capacity; ++i) pose_to7(poses[i], poses7 + 7 * i);
+  });
+}
+// state: [keyframe_created, pose_estimated, num_planned_ba_iterations, base keyframe id or -1, motion model length]
+int bsh_slam_state(void* slam, int* state) {
+  BSH_TRY({
+    BadSlam* s = static_cast<BadSlam*>(slam);
+    state[0] = s->keyframe_created(); state[1] = s->pose_estimated(); state[2] = s->num_planned_ba_iterations();
+    state[3] = s->base_kf() ? s->base_kf()->id() : -1;
+    state[4] = static_cast<int>(s->motion_model_base_kf_tr_frame().size());
   });
 }
 

@@ -89,6 +89,24 @@ Keyframe::Keyframe(bslam_context* ctx, hipStream_t stream, u32 frame_index, cons
   set_global_T_frame(global_T_frame);
 }
 
+template <typename T>
+static void CopyDeviceImage(hipStream_t stream, const DeviceBuffer<T>& from, DeviceBuffer<T>* to) {
+  if (from.width() != to->width() || from.height() != to->height()) throw std::invalid_argument("Keyframe: image sizes differ");
+  HIP_OR_THROW(hipMemcpy2DAsync(to->address(), to->pitch(), from.address(), from.pitch(), static_cast<size_t>(from.width()) * sizeof(T), from.height(),
+                                hipMemcpyDeviceToDevice, stream));
+}
+
+Keyframe::Keyframe(hipStream_t stream, u32 frame_index, float min_depth, float max_depth, const DeviceBuffer<u16>& depth, const DeviceBuffer<u16>& normals,
+                   const DeviceBuffer<u16>& radius, const DeviceBuffer<uchar4_t>& color, const SE3f& global_T_frame)
+    : frame_index_(frame_index), min_depth_(min_depth), max_depth_(max_depth), depth_(depth.height(), depth.width()),
+      normals_(normals.height(), normals.width()), radius_(radius.height(), radius.width()), color_(color.height(), color.width()) {
+  CopyDeviceImage(stream, depth, &depth_);
+  CopyDeviceImage(stream, normals, &normals_);
+  CopyDeviceImage(stream, radius, &radius_);
+  CopyDeviceImage(stream, color, &color_);
+  set_global_T_frame(global_T_frame);
+}
+
 bslam_keyframe_view Keyframe::view() const {
   bslam_keyframe_view v;
   v.depth = depth_.ToPod();

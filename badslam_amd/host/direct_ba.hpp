@@ -92,6 +92,10 @@ class Keyframe {
   Keyframe(bslam_context* ctx, hipStream_t stream, u32 frame_index, const bslam_depth_params& depth_params, const bslam_camera4f& depth_camera,
            const u16* depth_image, int color_width, int color_height, const u8* rgb_image, const SE3f& global_T_frame);
 
+  // The reference's prepared-buffer constructor proper (BS/keyframe.cc:35-80): DEVICE images, copied on `stream`.
+  Keyframe(hipStream_t stream, u32 frame_index, float min_depth, float max_depth, const DeviceBuffer<u16>& depth, const DeviceBuffer<u16>& normals,
+           const DeviceBuffer<u16>& radius, const DeviceBuffer<uchar4_t>& color, const SE3f& global_T_frame);
+
   const DeviceBuffer<u16>& depth_buffer() const { return depth_; }
   const DeviceBuffer<u16>& normals_buffer() const { return normals_; }
   const DeviceBuffer<u16>& radius_buffer() const { return radius_; }
