@@ -77,7 +77,10 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 #ifndef BSLAM_POSE_WAVES_GEO
 #define BSLAM_POSE_WAVES_GEO 6
 #endif
-#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? 4 : BSLAM_POSE_WAVES_GEO)))
+#ifndef BSLAM_POSE_WAVES_DESC
+#define BSLAM_POSE_WAVES_DESC 4
+#endif
+#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : BSLAM_POSE_WAVES_GEO)))
 template <bool kDepth, bool kDesc, int kPoseR>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
