@@ -380,10 +380,30 @@ __device__ __forceinline__ void point_value_and_gradient(const KfDev& kf, const 
 // raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers
 __device__ __forceinline__ void descriptor_residual_and_jacobian(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2, float d1, float d2,
                                                                  float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
-  float intensity, i1, i2, cdx, cdy, t1dx, t1dy, t2dx, t2dy;
-  point_value_and_gradient(kf, c, cp, &intensity, &cdx, &cdy);
-  point_value_and_gradient(kf, c, t1, &i1, &t1dx, &t1dy);
-  point_value_and_gradient(kf, c, t2, &i2, &t2dx, &t2dy);
+  // The three footprints first, then the three gathers back to back (one wait instead of three dependent
+  // load -> wait -> filter rounds), then the filters: same arithmetic as three point_value_and_gradient calls.
+  const f2 pts[3] = {cp, t1, t2};
+  TexFootprint f[3];
+  GradFootprint g[3];
+  uint32_t q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f[k] = tex_footprint(c, pts[k].x, pts[k].y);
+    g[k] = grad_footprint(c, pts[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = quad_at(kf, c, f[k].i, f[k].j);
+  float val[3], gx[3], gy[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const LumaQuad t = unpack_quad(q[k]);
+    LumaQuad tg = t;
+    if (g[k].ix != f[k].i || g[k].iy != f[k].j) tg = unpack_quad(quad_at(kf, c, g[k].ix, g[k].iy));   // only in the half-pixel border strip
+    val[k] = tex_filter(t, f[k].a, f[k].b);
+    grad_filter(tg, g[k], &gx[k], &gy[k]);
+  }
+  const float intensity = val[0], i1 = val[1], i2 = val[2];
+  const float cdx = gx[0], cdy = gy[0], t1dx = gx[1], t1dy = gy[1], t2dx = gx[2], t2dy = gy[2];
   *r1 = (180.f * (i1 - intensity)) - d1;
   *r2 = (180.f * (i2 - intensity)) - d2;
   *gx1 = 180.f * (t1dx - cdx);
