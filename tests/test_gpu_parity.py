@@ -361,3 +361,26 @@ def test_assign_colors_bit_exact(oracle, tex_mode):
     changed = want != sentinel
     assert changed.sum() > 0.9 * (n - 50) and not changed[n - 50:].any()
     assert len(np.unique(want[changed] & 0xff)) > 50 and len(np.unique((want[changed] >> 16) & 0xff)) > 50
+
+
+def test_keyframe_without_any_association_keeps_its_pose(oracle):
+    """A keyframe that sees none of the surfels: H = 0, b = 0.  Eigen's pivoted LDLT of the zero matrix solves to x = 0
+    (BS/direct_ba_alternating.cc:206), so the pose must come back unchanged and finite, flagged converged after one
+    iteration -- in the oracle and in the batched HIP loop alike, next to keyframes that do move."""
+    from tests import gpu_util
+    scene = scenes.synthetic_scene(3, seed=8, use_depth_residuals=True, use_descriptor_residuals=False)
+    far = scene.keyframes[2]
+    away = bso.se3_exp(np.array([50.0, 0, 0, 0, 0, 0], np.float32))
+    far.global_T_frame = bso.se3_mul(far.global_T_frame, away)
+    inits = [bso.se3_mul(kf.global_T_frame, bso.se3_exp(np.array([0.003, -0.002, 0.001, 0.0005, 0, -0.0005], np.float32))) for kf in scene.keyframes]
+    inits[2] = far.global_T_frame
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))
+    assert (hip.association(2) == 0xffffffff).all() or hip.accumulate_pose(2)["count"] == 0
+    poses, iters, conv = hip.estimate_poses_batched(inits)
+    got = bso.se3_to_np(poses[2])
+    assert np.isfinite(got).all() and np.array_equal(got, bso.se3_to_np(inits[2]))
+    assert conv[2] == 1 and iters[2] == 1
+    ref, ref_it, ref_conv = scene.estimate_frame_pose(far, inits[2])
+    assert np.array_equal(bso.se3_to_np(ref), bso.se3_to_np(inits[2])) and ref_conv and ref_it == 1
+    for k in (0, 1):   # the others are optimised as usual
+        assert conv[k] == 1 and iters[k] > 1
