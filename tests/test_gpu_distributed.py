@@ -86,6 +86,44 @@ def test_two_ranks_sharded_pose_estimation_matches_single_process(tmp_path, orac
     assert np.abs(single - truth).max() < 1e-4 < np.abs(_pose_array(init) - truth).max()
 
 
+def _nccl_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    from badslam_amd.distributed import AllReduceHook
+    from tests import bso, gpu_util
+    bso.build_oracle()
+    scene, init = _scene()
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))
+    hook = AllReduceHook(device=True)
+    poses, iters, conv = hip.estimate_poses_batched(init, allreduce=hook.callback)
+    torch.cuda.synchronize()
+    assert hook.calls >= 2
+    np.save(os.path.join(out_dir, "nccl_poses.npy"), _pose_array(poses))
+    np.save(os.path.join(out_dir, "nccl_iters.npy"), np.array(iters))
+    plain, plain_iters, _ = hip.estimate_poses_batched(init)
+    np.save(os.path.join(out_dir, "plain_poses.npy"), _pose_array(plain))
+    np.save(os.path.join(out_dir, "plain_iters.npy"), np.array(plain_iters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_hook_matches_the_plain_path(tmp_path, oracle):
+    """The production exchange itself: backend "nccl" (= RCCL) on the library's device buffer, aliased through
+    __cuda_array_interface__, ordered on the library's stream.  One GPU allows one rank, for which the all-reduce is the
+    identity: the hook path (row sum, exchange, solve as separate kernels) must reproduce the fused single-GPU path."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    a, b = np.load(tmp_path / "nccl_poses.npy"), np.load(tmp_path / "plain_poses.npy")
+    assert np.isfinite(a).all()
+    # same rows, same summation order inside a block; the two paths differ only in where the count column is split
+    assert np.abs(a - b).max() < 1e-6, np.abs(a - b).max()
+    assert np.array_equal(np.load(tmp_path / "nccl_iters.npy"), np.load(tmp_path / "plain_iters.npy"))
+
+
 # ------------------------------------------------------------------------------------------------
 # PCG and intrinsics under sharding, through the C++ host class
 # ------------------------------------------------------------------------------------------------
