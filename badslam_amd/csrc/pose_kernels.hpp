@@ -211,6 +211,21 @@ __global__ __launch_bounds__(64) void pose_reduce_final_kernel(const float* __re
   }
 }
 
+// Thread (sub, col) of a 1024-thread block adds column `col` of the rows sub, sub + 32, sub + 64, ... of one keyframe.
+// Eight independent partial sums keep eight loads in flight (the walk waits on memory, not on the adds); fixed order.
+__device__ __forceinline__ float column_share_of_rows(const float* __restrict__ base, int sub, int rows) {
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int r = sub;
+  for (; r + 7 * 32 < rows; r += 8 * 32) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] += base[(size_t)(r + 32 * u) * kRow];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (r + 32 * u < rows) v[u] += base[(size_t)(r + 32 * u) * kRow];
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
 // Both stages in one launch for the batched loop with an all-reduce hook: block k (1024 threads) sums keyframe k's
 // rows coalesced in the same fixed order as pose_reduce_solve_kernel and writes the coefficient row that goes through
 // the exchange (count as two exact 16-bit halves, as above).  Rows of converged keyframes are written as zeros, so
@@ -224,19 +239,7 @@ __global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __r
   }
   __shared__ float sm[32][kRow];
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  const float* base = partials + (size_t)k * rows_per_kf * kRow + col;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int r = sub;
-  for (; r + 96 < rows_per_kf; r += 128) {
-    v0 += base[(size_t)r * kRow];
-    v1 += base[(size_t)(r + 32) * kRow];
-    v2 += base[(size_t)(r + 64) * kRow];
-    v3 += base[(size_t)(r + 96) * kRow];
-  }
-  if (r < rows_per_kf) v0 += base[(size_t)r * kRow];
-  if (r + 32 < rows_per_kf) v1 += base[(size_t)(r + 32) * kRow];
-  if (r + 64 < rows_per_kf) v2 += base[(size_t)(r + 64) * kRow];
-  sm[sub][col] = ((v0 + v1) + v2) + v3;   // the count column: <= 256 per row, exact in fp32 up to 65k rows
+  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf);   // the count column: <= 256 per row, exact in fp32 up to 65k rows
   __syncthreads();
   if (threadIdx.x >= kRow) return;
   if (col == kRowCount) {
@@ -443,19 +446,7 @@ __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(
   __shared__ float row[kRow];
   __shared__ LdltWork work;
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  const float* base = partials + (size_t)k * rows_per_kf * kRow + col;
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int r = sub;
-  for (; r + 96 < rows_per_kf; r += 128) {
-    v0 += base[(size_t)r * kRow];
-    v1 += base[(size_t)(r + 32) * kRow];
-    v2 += base[(size_t)(r + 64) * kRow];
-    v3 += base[(size_t)(r + 96) * kRow];
-  }
-  if (r < rows_per_kf) v0 += base[(size_t)r * kRow];
-  if (r + 32 < rows_per_kf) v1 += base[(size_t)(r + 32) * kRow];
-  if (r + 64 < rows_per_kf) v2 += base[(size_t)(r + 64) * kRow];
-  sm[sub][col] = ((v0 + v1) + v2) + v3;
+  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf);
   __syncthreads();
   if (threadIdx.x < 27) {
     float total = 0.f;
