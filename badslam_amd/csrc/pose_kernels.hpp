@@ -347,44 +347,84 @@ __device__ inline void se3_inverse_matrix(Quat q, f3 t, float* m /*12*/) {
 // selfadjointView<Upper>().ldlt().solve() does at BS/direct_ba_alternating.cc:206).
 // The pivoting makes the indexing dynamic, which would put A / y / perm into scratch memory (global latency on every
 // access of a serial fp64 chain); the caller provides an LDS workspace instead.
-struct LdltWork { double A[36]; double temp[6]; double y[6]; int perm[6]; };
+struct LdltWork { double A[36]; double temp[6]; double y[6]; int perm[6]; };   // (kept for callers that size LDS by it)
 
-__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x, LdltWork* ws) {
+// Every loop below is unrolled to constant indices, so A, y and the transpositions live in registers; the dynamic pivot
+// index only selects which (constant-index) swap runs.  One thread per keyframe executes this as a serial fp64 chain:
+// with the workspace in LDS every dependent access cost ~100 cycles (17 us per Gauss-Newton iteration at K = 50),
+// in registers ~8.  Same operations in the same order as before: same bits.
+__device__ __forceinline__ void swap_d(double& a, double& b) { const double t = a; a = b; b = t; }
+
+__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x, LdltWork* /*unused*/) {
   constexpr int n = 6;
-  double* A = ws->A;
-  int idx = 0;
-  for (int r = 0; r < n; ++r)
-    for (int cc = r; cc < n; ++cc) { A[r * n + cc] = (double)H_upper[idx]; A[cc * n + r] = (double)H_upper[idx]; ++idx; }
-  int* perm = ws->perm;
+  double A[n][n];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int r = 0; r < n; ++r)
+#pragma unroll
+      for (int cc = r; cc < n; ++cc) { A[r][cc] = (double)H_upper[idx]; A[cc][r] = (double)H_upper[idx]; ++idx; }
+  }
+  int perm[n];
+#pragma unroll
   for (int k = 0; k < n; ++k) {
     int p = k;
-    double biggest = fabs(A[k * n + k]);
-    for (int i = k + 1; i < n; ++i) { const double v = fabs(A[i * n + i]); if (v > biggest) { biggest = v; p = i; } }
+    double biggest = fabs(A[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < n; ++i) { const double v = fabs(A[i][i]); if (v > biggest) { biggest = v; p = i; } }
     perm[k] = p;
-    if (p != k) {
-      for (int cc = 0; cc < n; ++cc) { const double tmp = A[k * n + cc]; A[k * n + cc] = A[p * n + cc]; A[p * n + cc] = tmp; }
-      for (int r = 0; r < n; ++r) { const double tmp = A[r * n + k]; A[r * n + k] = A[r * n + p]; A[r * n + p] = tmp; }
+#pragma unroll
+    for (int i = k + 1; i < n; ++i) {
+      if (p == i) {
+#pragma unroll
+        for (int cc = 0; cc < n; ++cc) swap_d(A[k][cc], A[i][cc]);
+#pragma unroll
+        for (int r = 0; r < n; ++r) swap_d(A[r][k], A[r][i]);
+      }
     }
-    double* temp = ws->temp;
-    for (int j = 0; j < k; ++j) temp[j] = A[j * n + j] * A[k * n + j];
+    double temp[n];
+#pragma unroll
+    for (int j = 0; j < k; ++j) temp[j] = A[j][j] * A[k][j];
     double acc = 0.0;
-    for (int j = 0; j < k; ++j) acc += A[k * n + j] * temp[j];
-    const double dk = A[k * n + k] - acc;
-    A[k * n + k] = dk;
+#pragma unroll
+    for (int j = 0; j < k; ++j) acc += A[k][j] * temp[j];
+    const double dk = A[k][k] - acc;
+    A[k][k] = dk;
+#pragma unroll
     for (int i = k + 1; i < n; ++i) {
       double sacc = 0.0;
-      for (int j = 0; j < k; ++j) sacc += A[i * n + j] * temp[j];
-      const double v = A[i * n + k] - sacc;
-      A[i * n + k] = (fabs(dk) > 0.0) ? v / dk : 0.0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) sacc += A[i][j] * temp[j];
+      const double v = A[i][k] - sacc;
+      A[i][k] = (fabs(dk) > 0.0) ? v / dk : 0.0;
     }
   }
-  double* y = ws->y;
+  double y[n];
+#pragma unroll
   for (int i = 0; i < n; ++i) y[i] = (double)b[i];
-  for (int k = 0; k < n; ++k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
-  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
-  for (int i = 0; i < n; ++i) { const double d = A[i * n + i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
-  for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
-  for (int k = n - 1; k >= 0; --k) if (perm[k] != k) { const double tmp = y[k]; y[k] = y[perm[k]]; y[perm[k]] = tmp; }
+#pragma unroll
+  for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < n; ++i)
+      if (perm[k] == i) swap_d(y[k], y[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { const double d = A[i][i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i)
+#pragma unroll
+    for (int j = i + 1; j < n; ++j) y[i] -= A[j][i] * y[j];
+#pragma unroll
+  for (int k = n - 1; k >= 0; --k) {
+#pragma unroll
+    for (int i = k + 1; i < n; ++i)
+      if (perm[k] == i) swap_d(y[k], y[i]);
+  }
+#pragma unroll
   for (int i = 0; i < n; ++i) x[i] = (float)y[i];
 }
 
