@@ -98,3 +98,28 @@ def test_stationary_camera_stays_put(oracle):
         slam.ProcessFrame(k, *frames[0])
     est = slam.frame_poses()
     assert np.abs(est[:, 4:7]).max() < 2e-4 and np.abs(est[:, :3]).max() < 1e-4
+
+
+def test_tum_directory_through_the_front_end_to_ate(oracle, tmp_path):
+    """The whole chain a user of the reference's `badslam <dataset>` needs: TUM directory (PNG depth / colour,
+    associated.txt, calibration.txt, groundtruth.txt) -> reader -> BadSlam::ProcessFrame per frame -> SavePoses -> ATE."""
+    from tests.test_io_cpu import write_png
+    from tools import run_tum
+    n = 9
+    cam, raw_to_float, frames, gt = render_sequence(n, seed=5)
+    (tmp_path / "rgb").mkdir()
+    (tmp_path / "depth").mkdir()
+    assoc, traj = [], ["# timestamp tx ty tz qx qy qz qw"]
+    for k, (depth, rgb) in enumerate(frames):
+        ts = f"{200.0 + 0.1 * k:.6f}"
+        write_png(tmp_path / "rgb" / f"{ts}.png", rgb, filter_type=k % 5)
+        write_png(tmp_path / "depth" / f"{ts}.png", depth, filter_type=(k + 1) % 5)
+        assoc.append(f"{ts} rgb/{ts}.png {ts} depth/{ts}.png")
+        q = bso.se3_to_np(gt[k])
+        traj.append(f"{ts} {q[4]:.9g} {q[5]:.9g} {q[6]:.9g} {q[0]:.9g} {q[1]:.9g} {q[2]:.9g} {q[3]:.9g}")
+    (tmp_path / "associated.txt").write_text("\n".join(assoc) + "\n")
+    (tmp_path / "calibration.txt").write_text(f"{cam.fx} {cam.fy} {cam.cx - 0.5} {cam.cy - 0.5}\n")   # pixel-centre convention on disk
+    (tmp_path / "groundtruth.txt").write_text("\n".join(traj) + "\n")
+    r = run_tum.run(tmp_path, trajectory="groundtruth.txt", keyframe_interval=4, ba_iterations=5, max_depth=6.0, num_scales=4, max_surfel_count=400000)
+    assert r["frames"] == n and r["keyframes"] == 3 and r["surfels"] > 5000
+    assert r["ate"]["pairs"] == n and r["ate"]["rmse"] < 2e-3, r["ate"]["rmse"]
