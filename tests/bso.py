@@ -240,10 +240,11 @@ class HostScene:
         depth = np.zeros((h, w), np.uint16)
         normals = np.zeros((h, w), np.uint16)
         radius = np.zeros((h, w), np.uint16)
-        color = np.zeros((h, w, 4), np.uint8)
         rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+        ch, cw = rgb.shape[:2]                       # the colour camera may have its own resolution
+        color = np.zeros((ch, cw, 4), np.uint8)
         cb = np_buffer2d(color)
-        L.bso_compute_brightness(w, h, rgb.ctypes.data, C.byref(cb))
+        L.bso_compute_brightness(cw, ch, rgb.ctypes.data, C.byref(cb))
         dp = self.depth_params()
         mn, mx = C.c_float(), C.c_float()
         bi, bd, bn, br = np_buffer2d(depth_in), np_buffer2d(depth), np_buffer2d(normals), np_buffer2d(radius)

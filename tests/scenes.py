@@ -237,15 +237,18 @@ def texture_at(points, planes_idx, seed_phase):
 def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, max_surfels=None,
                     use_depth_residuals=True, use_descriptor_residuals=False,
                     translation_range=0.25, rotation_range=0.12, depth_max_m=6.0,
-                    camera=None, tex_mode=abi.TEX_FIXED_POINT_1_8):
+                    camera=None, tex_mode=abi.TEX_FIXED_POINT_1_8, color_scale=1):
     """Synthetic 640x480 keyframe stack of SURVEY.md 8(d): random planes, photo-consistent
-    texture, keyframe poses T0 * exp(xi); surfels created keyframe by keyframe at `cell`."""
+    texture, keyframe poses T0 * exp(xi); surfels created keyframe by keyframe at `cell`.
+    color_scale = s > 1: the colour camera has s times the resolution of the depth camera (same pose and field of view)."""
     rng = np.random.default_rng(seed)
     cam = camera or bso.make_camera(525.0, 525.0, 319.5 + 0.5, 239.5 + 0.5, width, height)
+    color_cam = cam if color_scale == 1 else bso.make_camera(cam.fx * color_scale, cam.fy * color_scale, cam.cx * color_scale, cam.cy * color_scale,
+                                                             width * color_scale, height * color_scale)
     raw_to_float_depth = np.float32(1.0 / 5000)
     if max_surfels is None:
         max_surfels = ((width - 1) // cell + 1) * ((height - 1) // cell + 1) * num_keyframes
-    scene = bso.HostScene(cam, cam, float(raw_to_float_depth), 40.0, cell, max_surfels,
+    scene = bso.HostScene(color_cam, cam, float(raw_to_float_depth), 40.0, cell, max_surfels,
                           use_depth_residuals=use_depth_residuals, use_descriptor_residuals=use_descriptor_residuals,
                           tex_mode=tex_mode)
     planes = random_planes(rng, 20)
@@ -260,8 +263,14 @@ def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, ma
         valid = np.isfinite(z) & (z < depth_max_m)
         depth = np.where(valid, z / float(raw_to_float_depth) + 0.5, 65535).astype(np.uint32)
         depth = np.where(depth >= 32768, 65535, depth).astype(np.uint16)
-        pts = o[None, None, :] + dg * np.where(valid, tt, 0.0)[..., None]
-        lum = texture_at(pts, pidx, 0.37)
+        if color_scale == 1:
+            pts = o[None, None, :] + dg * np.where(valid, tt, 0.0)[..., None]
+            lum = texture_at(pts, pidx, 0.37)
+        else:   # the same surface seen through the finer colour pixel grid
+            ctt, cpidx, cdg, co = render_planes(color_cam, width * color_scale, height * color_scale, R, t, planes)
+            cvalid = np.isfinite(ctt)
+            cpts = co[None, None, :] + cdg * np.where(cvalid, ctt, 0.0)[..., None]
+            lum = texture_at(cpts, cpidx, 0.37)
         rgb = np.repeat(lum[:, :, None], 3, axis=2)
         kf = scene.add_keyframe_from_images(depth, rgb, T)
         scene.create_surfels_for_keyframe(kf)

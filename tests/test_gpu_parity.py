@@ -384,3 +384,33 @@ def test_keyframe_without_any_association_keeps_its_pose(oracle):
     assert np.array_equal(bso.se3_to_np(ref), bso.se3_to_np(inits[2])) and ref_conv and ref_it == 1
     for k in (0, 1):   # the others are optimised as usual
         assert conv[k] == 1 and iters[k] > 1
+
+
+def test_color_camera_with_its_own_resolution(oracle):
+    """Colour camera at twice the depth camera's resolution (the reference supports separate depth / colour intrinsics
+    and sizes, BS/surfel_projection.cuh:184-207): the depth-to-colour transform, the luma-quad table of the larger image and
+    the colour bounds test all have to use the colour camera's own dimensions."""
+    from tests import gpu_util
+    cam = bso.make_camera(262.5, 262.5, 160.0, 120.0, 320, 240)
+    scene = scenes.synthetic_scene(3, seed=12, width=320, height=240, camera=cam, use_depth_residuals=True, use_descriptor_residuals=True, color_scale=2)
+    assert scene.keyframes[0].color.shape == (480, 640, 4) and scene.keyframes[0].depth.shape == (240, 320)
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))
+    for k, kf in enumerate(scene.keyframes):
+        assert np.array_equal(scene.association(kf), hip.association(k))
+        ref = scene.accumulate_pose(kf)
+        got = hip.accumulate_pose(k)
+        assert got["count"] == ref["count"] and ref["count"] > 5000
+        assert np.abs(got["H"] - ref["H64"]).max() <= 1e-4 * np.abs(ref["H64"]).max()
+        assert np.abs(got["b"] - ref["b64"]).max() <= 1e-4 * max(np.abs(ref["b64"]).max(), 1e-3 * np.abs(ref["H64"]).max())
+    # colours and the joint position + descriptor step
+    hip.assign_colors()
+    scene.assign_colors()
+    n = scene.surfels_size
+    assert np.array_equal(hip.d.surfels_np()[5, :n].view(np.uint32), scene.surfels[5, :n].view(np.uint32))
+    scene.update_activation()
+    hip.update_activation()
+    scene.optimize_geometry_iteration()
+    hip.optimize_geometry_iteration()
+    got = hip.d.surfels_np()[:8, :n]
+    assert np.abs(got[:3] - scene.surfels[:3, :n]).max() < 1e-5
+    assert np.abs(got[6:8] - scene.surfels[6:8, :n]).max() < 1e-3      # descriptors live on a scale of 180
