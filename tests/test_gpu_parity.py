@@ -414,3 +414,34 @@ def test_color_camera_with_its_own_resolution(oracle):
     got = hip.d.surfels_np()[:8, :n]
     assert np.abs(got[:3] - scene.surfels[:3, :n]).max() < 1e-5
     assert np.abs(got[6:8] - scene.surfels[6:8, :n]).max() < 1e-3      # descriptors live on a scale of 180
+
+
+def test_many_small_keyframes(oracle):
+    """K = 70 keyframes of 160 x 120: nothing in the batched kernels may assume K <= 64 (keyframe chunks per block, the
+    per-keyframe reduce blocks, the convergence counter) or a 640 x 480 image."""
+    from tests import gpu_util
+    cam = bso.make_camera(131.25, 131.25, 80.0, 60.0, 160, 120)
+    scene = scenes.synthetic_scene(70, seed=13, width=160, height=120, camera=cam, use_depth_residuals=True, use_descriptor_residuals=False)
+    K = len(scene.keyframes)
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))
+    Hb, counts = hip.accumulate_pose_batched()
+    for k in (0, 1, 33, 63, 64, 65, 69):
+        ref = scene.accumulate_pose(scene.keyframes[k])
+        assert counts[k] == ref["count"]
+        assert np.abs(Hb[k, :21] - ref["H64"]).max() <= 1e-4 * np.abs(ref["H64"]).max()
+    rng = np.random.default_rng(1)
+    inits = [bso.se3_mul(kf.global_T_frame, bso.se3_exp(np.concatenate([rng.choice([-1, 1], 3) * 0.003, rng.choice([-1, 1], 3) * 0.0007]).astype(np.float32)))
+             for kf in scene.keyframes]
+    poses, iters, conv = hip.estimate_poses_batched(inits)
+    assert all(conv) and max(iters) < 30
+    for k in (0, 63, 64, 69):
+        ref, _, _ = scene.estimate_frame_pose(scene.keyframes[k], inits[k])
+        assert np.abs(bso.se3_to_np(poses[k]) - bso.se3_to_np(ref)).max() < 1e-5
+    scene.update_activation()
+    hip.update_activation()
+    assert np.array_equal(hip.d.active_np()[0, :scene.surfels_size], scene.active[0, :scene.surfels_size])
+    scene.optimize_geometry_iteration()
+    hip.optimize_geometry_iteration()
+    n = scene.surfels_size
+    assert np.array_equal(hip.d.surfels_np()[3, :n].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
+    assert np.abs(hip.d.surfels_np()[:3, :n] - scene.surfels[:3, :n]).max() < 1e-5
