@@ -275,7 +275,14 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
   int chunks = (target_blocks + tiles - 1) / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > kf_count) chunks = kf_count;
-  return (kf_count + chunks - 1) / chunks;
+  int per_block = (kf_count + chunks - 1) / chunks;
+  // Large surfel counts give enough blocks with one chunk, but then every block walks the whole keyframe list and the
+  // resident blocks spread over all of it; a cap keeps the blocks in flight (chunk-major order) on a few keyframes.
+#ifndef BSLAM_POSE_MAX_KFS_PER_BLOCK
+#define BSLAM_POSE_MAX_KFS_PER_BLOCK 16   /* measured flat optimum 12 ... 32 (K = 200: -7 %, K = 300 photometric: -13 % kernel time); 0: no cap */
+#endif
+  if (BSLAM_POSE_MAX_KFS_PER_BLOCK > 0 && per_block > BSLAM_POSE_MAX_KFS_PER_BLOCK) per_block = BSLAM_POSE_MAX_KFS_PER_BLOCK;
+  return per_block;
 }
 
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
