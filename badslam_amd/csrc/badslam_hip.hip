@@ -426,6 +426,12 @@ int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float*
   return BSLAM_OK;
 }
 
+int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch) {
+  if (!ctx || keyframes_per_launch < 0) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad argument");
+  ctx->geom_kf_chunk = keyframes_per_launch;
+  return BSLAM_OK;
+}
+
 int bslam_assign_colors(
     bslam_context* ctx, void* stream_, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
     const bslam_depth_params* depth_params, int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size,
@@ -751,9 +757,28 @@ int bslam_optimize_geometry_iteration(
 #define BSLAM_GEOM_WG_PER_CU 5
 #endif
     const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU) / 8u);   // slots per XCD and launch
+    // keyframes per launch (bslam_set_geometry_keyframe_chunk; default 128: K = 200: geometry kernel 6.9 -> 5.5 ms)
+    const int kf_chunk = ctx->geom_kf_chunk;
+    float* acc = nullptr;
+    uint32_t acc_pitch = 0;
+    if (kf_chunk > 0 && keyframe_count > kf_chunk) {
+      acc_pitch = (surfels_size + 63u) & ~63u;
+      if ((rc = ctx->exchange.reserve((size_t)acc_pitch * 4 * sizeof(float)))) return rc;
+      acc = (float*)ctx->exchange.ptr;
+    }
     for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
       const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
-      hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), dim3(8u * n), block, 0, stream, c, kfs, keyframe_count, sc, first, rows);
+      if (!acc) {
+        hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), dim3(8u * n), block, 0, stream, c, kfs, keyframe_count, sc, first, rows);
+        continue;
+      }
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int k0 = 0; k0 < keyframe_count; k0 += kf_chunk) {
+          const int k1 = std::min(keyframe_count, k0 + kf_chunk);
+          if (pass == 0) hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 0>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, first, rows, acc, acc_pitch);
+          else hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 1>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, first, rows, acc, acc_pitch);
+        }
+      }
     }
   }
   else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);

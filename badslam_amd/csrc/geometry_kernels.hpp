@@ -411,4 +411,77 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
   }
 }
 
+// The same two passes for long keyframe lists, one launch per chunk of keyframes: the per-surfel sums travel between the
+// launches in library scratch (acc: 4 floats per surfel), so the workgroups of a resident grid re-align at every chunk
+// boundary instead of drifting apart over hundreds of keyframes.  Sums are still formed in keyframe order: same bits as
+// the single-launch kernel.  pass 0: normals (acc = sx, sy, sz, count), pass 1: position (acc = H, b).
+template <int R, int kPass>
+__global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
+                                                            Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x + (first_i << 3), &slot)) return;
+  uint32_t idx[R];
+  bool on[R];
+  f3 gp[R], gn[R];
+  float a0[R], a1[R], a2[R], a3[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    idx[r] = surfel_of_slot(sc, slot, r, R);
+    on[r] = idx[r] < s.size;
+    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    const uint32_t j = on[r] ? idx[r] : 0;
+    gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
+    gn[r] = unpack_normal(s.normal[j]);
+    a0[r] = a1[r] = a2[r] = a3[r] = 0.f;
+    if (!first_chunk && on[r]) {
+      a0[r] = acc[j]; a1[r] = acc[(size_t)acc_pitch + j];
+      if (kPass == 0) { a2[r] = acc[(size_t)2 * acc_pitch + j]; a3[r] = acc[(size_t)3 * acc_pitch + j]; }
+    }
+  }
+  for (int k = k_begin; k < k_end; ++k) {
+    const KfDev kf = kfs[k];
+    if (kf.activation == BSLAM_KF_INACTIVE) continue;
+    const float* Rm = kf.global_R_frame;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Proj p;
+      if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      if (kPass == 0) {
+        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        a0[r] += rot_row(Rm[0], Rm[1], Rm[2], ln);
+        a1[r] += rot_row(Rm[3], Rm[4], Rm[5], ln);
+        a2[r] += rot_row(Rm[6], Rm[7], Rm[8], ln);
+        a3[r] += 1.f;
+      } else {
+        const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
+        const float dj = -inv_stddev;
+        const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);
+        const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+        const float w = depth_weight(raw);
+        const float wj = w * dj;
+        a0[r] += wj * dj;
+        a1[r] += wj * raw;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!on[r]) continue;
+    const uint32_t j = idx[r];
+    if (!last_chunk) {
+      acc[j] = a0[r]; acc[(size_t)acc_pitch + j] = a1[r];
+      if (kPass == 0) { acc[(size_t)2 * acc_pitch + j] = a2[r]; acc[(size_t)3 * acc_pitch + j] = a3[r]; }
+    } else if (kPass == 0) {
+      if (a3[r] >= 1) {
+        const float inv = 1.f / a3[r];
+        s.normal[j] = pack_normal(mk3(inv * a0[r], inv * a1[r], inv * a2[r]));
+      }
+    } else if (a0[r] > 1e-6f) {
+      const float t = -1.f * a1[r] / a0[r];
+      const f3 np = add3(gp[r], scale3(t, gn[r]));
+      s.x[j] = np.x; s.y[j] = np.y; s.z[j] = np.z;
+    }
+  }
+}
+
 }  // namespace bslam

@@ -310,6 +310,11 @@ int bslam_debug_association(
     uint32_t surfels_size, const bslam_buffer2d* surfels,
     uint32_t* out_pixel);
 
+/* Tuning knob of bslam_optimize_geometry_iteration (geometry-only mode): long keyframe lists are walked in launches of
+ * at most `keyframes_per_launch` keyframes, with the per-surfel sums carried in library scratch (results are bit-identical
+ * to a single launch).  Default 128; 0 = always one launch. */
+int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch);
+
 /* Replaces AssignColorsCUDA (BS/kernels.h:301-308, BS/kernel_assign_colors.cc:40-80, .cu:42-125): every surfel's
  * colour row becomes the mean of the bilinearly filtered uchar4 colours of the pixels it is associated with over ALL
  * listed keyframes (activation is ignored, as in the reference); surfels without an observation keep their colour.

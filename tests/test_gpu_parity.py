@@ -6,6 +6,8 @@ H/b coefficients and optimised poses within 1e-4 relative (tolerances written at
 import ctypes as C
 
 import numpy as np
+
+import badslam_amd
 import pytest
 
 from badslam_amd import abi
@@ -440,8 +442,18 @@ def test_many_small_keyframes(oracle):
     scene.update_activation()
     hip.update_activation()
     assert np.array_equal(hip.d.active_np()[0, :scene.surfels_size], scene.active[0, :scene.surfels_size])
-    scene.optimize_geometry_iteration()
-    hip.optimize_geometry_iteration()
+    # the geometry iteration twice from the same state: in one launch over all 70 keyframes, and in launches of 16
+    # keyframes with the per-surfel sums carried between them -- bit-identical to each other, and equal to the oracle
     n = scene.surfels_size
-    assert np.array_equal(hip.d.surfels_np()[3, :n].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
-    assert np.abs(hip.d.surfels_np()[:3, :n] - scene.surfels[:3, :n]).max() < 1e-5
+    start = hip.d.surfels.clone()
+    badslam_amd.check(hip.L.bslam_set_geometry_keyframe_chunk(hip.ctx.handle, 0))
+    hip.optimize_geometry_iteration()
+    single = hip.d.surfels_np()[:8, :n].copy()
+    hip.d.surfels.copy_(start)
+    badslam_amd.check(hip.L.bslam_set_geometry_keyframe_chunk(hip.ctx.handle, 16))
+    hip.optimize_geometry_iteration()
+    chunked = hip.d.surfels_np()[:8, :n]
+    assert np.array_equal(single.view(np.uint32), chunked.view(np.uint32))
+    scene.optimize_geometry_iteration()
+    assert np.array_equal(chunked[3].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
+    assert np.abs(chunked[:3] - scene.surfels[:3, :n]).max() < 1e-5
