@@ -89,6 +89,8 @@ def main():
     L = badslam_amd.lib()
     ctx = badslam_amd.Context(dev_index)
     L.bslam_set_keyframe_cache(ctx.handle, 1)   # the bench never rewrites a keyframe image in place
+    if os.environ.get("BSLAM_GEOM_KF_CHUNK"):   # tuning runs only; the default is the library's
+        badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(ctx.handle, int(os.environ["BSLAM_GEOM_KF_CHUNK"])))
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     dp = dev.depth_params()
     sb, ab = dev.buf(dev.surfels), dev.buf(dev.active)
