@@ -345,17 +345,13 @@ __device__ inline void se3_inverse_matrix(Quat q, f3 t, float* m /*12*/) {
 
 // 6x6 symmetric solve in double: LDL^T with diagonal pivoting (what Eigen's
 // selfadjointView<Upper>().ldlt().solve() does at BS/direct_ba_alternating.cc:206).
-// The pivoting makes the indexing dynamic, which would put A / y / perm into scratch memory (global latency on every
-// access of a serial fp64 chain); the caller provides an LDS workspace instead.
-struct LdltWork { double A[36]; double temp[6]; double y[6]; int perm[6]; };   // (kept for callers that size LDS by it)
-
 // Every loop below is unrolled to constant indices, so A, y and the transpositions live in registers; the dynamic pivot
 // index only selects which (constant-index) swap runs.  One thread per keyframe executes this as a serial fp64 chain:
 // with the workspace in LDS every dependent access cost ~100 cycles (17 us per Gauss-Newton iteration at K = 50),
-// in registers ~8.  Same operations in the same order as before: same bits.
+// in registers ~8.
 __device__ __forceinline__ void swap_d(double& a, double& b) { const double t = a; a = b; b = t; }
 
-__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x, LdltWork* /*unused*/) {
+__device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* x) {
   constexpr int n = 6;
   double A[n][n];
   {
@@ -445,11 +441,10 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
   if (k >= kf_count) return;
   PoseState st = states[k];
   if (st.converged) return;
-  __shared__ LdltWork work[64];
   float H[21], b[6], x[6];
   for (int i = 0; i < 21; ++i) H[i] = coeffs[(size_t)k * kRow + i];
   for (int i = 0; i < 6; ++i) b[i] = coeffs[(size_t)k * kRow + 21 + i];
-  solve_ldlt6(H, b, x, &work[threadIdx.x]);
+  solve_ldlt6(H, b, x);
   float neg[6];
   for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
   Quat dq; f3 dt;
@@ -474,7 +469,7 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
 // between).  Block k sums the per-wave rows [rows][32] of keyframe k -- thread (sub, col) owns the rows r = sub mod 32 of
 // column col and keeps four independent partial sums for memory-level parallelism; the 32 per-thread sums of a column
 // are then added in a fixed order (deterministic) -- and thread 0 does the fp64 pivoted LDL^T, the SE3 update and the
-// convergence test with its workspace in LDS.
+// convergence test (LDL^T unrolled in registers).
 constexpr int kReduceSolveThreads = 1024;
 __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                                PoseState* __restrict__ states, KfDev* __restrict__ kfs,
@@ -484,7 +479,6 @@ __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(
   if (states[k].converged) return;   // uniform
   __shared__ float sm[32][kRow];
   __shared__ float row[kRow];
-  __shared__ LdltWork work;
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
   sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf);
   __syncthreads();
@@ -499,7 +493,7 @@ __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(
   float H[21], b[6], x[6];
   for (int i = 0; i < 21; ++i) H[i] = row[i];
   for (int i = 0; i < 6; ++i) b[i] = row[21 + i];
-  solve_ldlt6(H, b, x, &work);
+  solve_ldlt6(H, b, x);
   float neg[6];
   for (int i = 0; i < 6; ++i) neg[i] = -1.f * x[i];
   Quat dq; f3 dt;

@@ -290,6 +290,60 @@ void bso_association(const bslam_camera4f* depth_camera, const bslam_depth_param
   }
 }
 
+/* Evaluation-shape switch of bso_math.h (0: twin of the HIP kernels, 1: literal transcription of the reference). */
+int bso_literal_mode = 0;
+void bso_set_literal_mode(int mode) { bso_literal_mode = mode != 0; }
+int bso_get_literal_mode(void) { return bso_literal_mode; }
+
+/* Decision margins of the association chain for every surfel, evaluated in float64 from the same inputs (diagnosis aid of
+ * tests/test_oracle_literal.py: a surfel whose integer output differs between the two evaluation shapes must sit on a
+ * threshold).  out[5 * i + ...] = { local z,
+ *   distance of (u, v) to the nearest pixel boundary or image border [px],
+ *   (threshold - |z - depth|) / threshold of the depth test (BS/surfel_projection_nvcc_only.cuh:88-100),
+ *   -cos(angle between viewing ray and surfel normal)            (:103-108),
+ *   dot(surfel normal, pixel normal) - cos 40 deg               (:111-121) };
+ * entries after the first failed stage are NaN. */
+void bso_association_margins(const bslam_camera4f* depth_camera, const bslam_depth_params* dp, const bslam_keyframe_view* kf,
+                             uint32_t surfels_size, const bslam_buffer2d* surfels, double* out) {
+  const double fx = depth_camera->fx, fy = depth_camera->fy, cx = depth_camera->cx, cy = depth_camera->cy;
+  const float* m = kf->frame_T_global.m;
+  for (uint32_t i = 0; i < surfels_size; ++i) {
+    double* o = out + 5 * (size_t)i;
+    for (int k = 0; k < 5; ++k) o[k] = NAN;
+    const bso_f3 gpf = bso_surfel_position(surfels, i);
+    const double g[3] = {gpf.x, gpf.y, gpf.z};
+    double l[3];
+    for (int r = 0; r < 3; ++r) l[r] = (double)m[4 * r] * g[0] + (double)m[4 * r + 1] * g[1] + (double)m[4 * r + 2] * g[2] + (double)m[4 * r + 3];
+    o[0] = l[2];
+    if (!(l[2] > 0)) continue;
+    const double u = fx * (l[0] / l[2]) + cx, v = fy * (l[1] / l[2]) + cy;
+    const double du = fmin(u - floor(u), ceil(u) - u), dv = fmin(v - floor(v), ceil(v) - v);
+    o[1] = fmin(fmin(du, dv), fmin(fmin(u, v), fmin(kf->depth.width - u, kf->depth.height - v)));
+    if (u < 0 || v < 0 || u >= kf->depth.width || v >= kf->depth.height) continue;
+    const int px = (int)u, py = (int)v;
+    const uint16_t measured = BSO_AT(uint16_t, &kf->depth, py, px);
+    if (measured & BSLAM_INVALID_DEPTH_BIT) continue;
+    const double cf = BSO_AT(float, &dp->cfactor_buffer, py / dp->sparse_surfel_cell_size, px / dp->sparse_surfel_cell_size);
+    const double inv_depth = 1.0 / ((double)dp->raw_to_float_depth * measured);
+    const double depth = 1.0 / (inv_depth + cf * exp(-(double)dp->a * inv_depth));
+    const bso_f3 nf = bso_surfel_normal(surfels, i);
+    double n[3];
+    for (int r = 0; r < 3; ++r) n[r] = (double)m[4 * r] * nf.x + (double)m[4 * r + 1] * nf.y + (double)m[4 * r + 2] * nf.z;
+    const double fx_inv = 1.0 / fx, fy_inv = 1.0 / fy;
+    const double nx = fx_inv * px - (cx - 0.5) * fx_inv, ny = fy_inv * py - (cy - 0.5) * fy_inv;
+    const double thr = 10.0 * (0.1 * fabs(n[0] * nx + n[1] * ny + n[2]) * depth * depth) / (double)dp->baseline_fx;
+    o[2] = (thr - fabs(l[2] - depth)) / thr;
+    if (fabs(l[2] - depth) > thr) continue;
+    o[3] = -(l[0] * n[0] + l[1] * n[1] + l[2] * n[2]) / sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+    if (o[3] < 0) continue;
+    const uint16_t pn = BSO_AT(uint16_t, &kf->normals, py, px);
+    const double pnx = (int8_t)(pn & 0xff) / 127.0, pny = (int8_t)(pn >> 8) / 127.0;
+    const double pz2 = 1.0 - pnx * pnx - pny * pny;
+    const double pnz = -sqrt(pz2 > 0 ? pz2 : 0);
+    o[4] = (n[0] * pnx + n[1] * pny + n[2] * pnz) - (double)BSO_COS_NORMAL_COMPAT;
+  }
+}
+
 /* ========================================================================== */
 /* pose optimisation                                                           */
 /* ========================================================================== */

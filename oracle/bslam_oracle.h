@@ -243,6 +243,12 @@ void bso_track_frame_pairwise(
     const bslam_buffer2d* base_depth_u16, const bslam_buffer2d* base_normals, const bslam_buffer2d* base_color_uchar4, int tex_mode,
     int test_different_initial_estimates, const bslam_se3f* init1, const bslam_se3f* init2, bslam_se3f* out_base_T_frame, int* iterations_per_scale);
 
+/* evaluation shape of bso_math.h: 0 = twin of the HIP kernels (default), 1 = literal transcription of the reference */
+void bso_set_literal_mode(int mode);
+int bso_get_literal_mode(void);
+void bso_association_margins(const bslam_camera4f* depth_camera, const bslam_depth_params* dp, const bslam_keyframe_view* kf,
+                             uint32_t surfels_size, const bslam_buffer2d* surfels, double* out);
+
 #ifdef __cplusplus
 }
 #endif

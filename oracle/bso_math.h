@@ -2,16 +2,28 @@
  * bso_math.h -- ORACLE (test infrastructure, never shipped, never on the product path).
  *
  * Plain-C restatement of the device math of the reference's bundle-adjustment hot
- * path.  Every function cites the reference file:line it follows; the arithmetic is
- * fp32 in the reference's operand order, compiled with -ffp-contract=off so that no
- * FMA is formed (the HIP kernels are built the same way, which is what makes the
- * integer outputs -- associated pixel, activation mask -- comparable bit for bit).
+ * path.  Every function cites the reference file:line it follows.  The arithmetic is
+ * fp32 and exists in TWO evaluation shapes, selected at run time by bso_literal_mode:
+ *
+ *   twin mode (0, default): the shape the HIP kernels use -- sums of products as explicit
+ *     fmaf chains (BSO_FMA below), ONE correctly rounded reciprocal per projection
+ *     (p.x * (1 / p.z)), "* fl(1 / baseline_fx)", the Cephes-style bso_expf.  Compiled with
+ *     -ffp-contract=off, so the only fused operations are the ones spelled out; the kernels
+ *     spell out the same ones, which is what makes the integer outputs (associated pixel,
+ *     activation mask, packed normals) comparable bit for bit between CPU and GPU.
+ *   literal mode (1): the reference's source expressions transcribed operator by operator in
+ *     its operand order, unfused and with IEEE division: fx * (x / z) + cx
+ *     (BS/surfel_projection.cuh:52-55), a.x*b.x + a.y*b.y + a.z*b.z (BS/cuda_util.cuh:52-58),
+ *     row.x*p.x + row.y*p.y + row.z*p.z + row.w (BS/cuda_matrix.cuh:98-137),
+ *     (...) / baseline_fx (BS/cost_function.cuh:81-83), 1 - x*x - y*y (BS/util.cuh:126), libm expf.
+ *     tests/test_oracle_literal.py measures how far the twin has moved from this transcription:
+ *     integer outputs may differ only on threshold ties, float outputs by rounding.
  *
  * BS/ = /root/reference/applications/badslam/src/badslam/
  *
- * Known, documented deviations from what the CUDA build computes:
- *   - the reference is compiled with -use_fast_math (approximate division / sqrtf /
- *     expf); this restatement uses IEEE division, sqrtf and bso_expf (below);
+ * Known, documented deviations of BOTH modes from what the CUDA build computes:
+ *   - the reference is compiled with -use_fast_math (approximate division / sqrtf / expf and
+ *     FMA contraction wherever nvcc likes), so its own last bits are not defined by its source;
  *   - tex2D() bilinear filtering is modelled in software (bso_tex_w below).
  */
 #ifndef BSO_MATH_H_
@@ -22,6 +34,11 @@
 #include <string.h>
 
 #include "../include/badslam_hip.h"
+
+/* 0: twin of the HIP kernels (default); 1: literal transcription of the reference's expressions.  Defined in
+ * bslam_oracle.c, set with bso_set_literal_mode(). */
+extern int bso_literal_mode;
+#define BSO_LITERAL __builtin_expect(bso_literal_mode != 0, 0)
 
 typedef struct { float x, y, z; } bso_f3;
 typedef struct { float x, y; } bso_f2;
@@ -44,11 +61,23 @@ static inline int bso_f2i(float v) {
  * (so the integer outputs stay bit-comparable) and costs the kernels half the instructions.  -ffp-contract=off stays:
  * nothing is fused implicitly. */
 #define BSO_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
-static inline float bso_sqlen(bso_f3 v) { return BSO_FMA(v.z, v.z, BSO_FMA(v.y, v.y, v.x * v.x)); }           /* :52 */
-static inline float bso_dot(bso_f3 a, bso_f3 b) { return BSO_FMA(a.z, b.z, BSO_FMA(a.y, b.y, a.x * b.x)); }   /* :57 */
-/* one row of a rigid transform / of a rotation applied to p */
-static inline float bso_tr_row(float a, float b, float c, float d, bso_f3 p) { return BSO_FMA(c, p.z, BSO_FMA(b, p.y, BSO_FMA(a, p.x, d))); }
-static inline float bso_rot_row(float a, float b, float c, bso_f3 p) { return BSO_FMA(c, p.z, BSO_FMA(b, p.y, a * p.x)); }
+static inline float bso_sqlen(bso_f3 v) {                                                        /* :52 */
+  if (BSO_LITERAL) return v.x * v.x + v.y * v.y + v.z * v.z;
+  return BSO_FMA(v.z, v.z, BSO_FMA(v.y, v.y, v.x * v.x));
+}
+static inline float bso_dot(bso_f3 a, bso_f3 b) {                                                /* :57 */
+  if (BSO_LITERAL) return a.x * b.x + a.y * b.y + a.z * b.z;
+  return BSO_FMA(a.z, b.z, BSO_FMA(a.y, b.y, a.x * b.x));
+}
+/* one row of a rigid transform / of a rotation applied to p (BS/cuda_matrix.cuh:98-137) */
+static inline float bso_tr_row(float a, float b, float c, float d, bso_f3 p) {
+  if (BSO_LITERAL) return a * p.x + b * p.y + c * p.z + d;
+  return BSO_FMA(c, p.z, BSO_FMA(b, p.y, BSO_FMA(a, p.x, d)));
+}
+static inline float bso_rot_row(float a, float b, float c, bso_f3 p) {
+  if (BSO_LITERAL) return a * p.x + b * p.y + c * p.z;
+  return BSO_FMA(c, p.z, BSO_FMA(b, p.y, a * p.x));
+}
 static inline bso_f3 bso_cross(bso_f3 a, bso_f3 b) {                                            /* :78 */
   return bso_make3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
@@ -97,8 +126,14 @@ static inline bso_unprojector bso_make_unprojector(const bslam_camera4f* c) {   
   u.cy_inv = -cy_pixel_center * u.fy_inv;
   return u;
 }
-static inline float bso_unproj_nx(const bso_unprojector* u, float px) { return BSO_FMA(u->fx_inv, px, u->cx_inv); }  /* BS/surfel_projection.cuh:116 */
-static inline float bso_unproj_ny(const bso_unprojector* u, float py) { return BSO_FMA(u->fy_inv, py, u->cy_inv); }
+static inline float bso_unproj_nx(const bso_unprojector* u, float px) {   /* BS/surfel_projection.cuh:116 */
+  if (BSO_LITERAL) return u->fx_inv * px + u->cx_inv;
+  return BSO_FMA(u->fx_inv, px, u->cx_inv);
+}
+static inline float bso_unproj_ny(const bso_unprojector* u, float py) {
+  if (BSO_LITERAL) return u->fy_inv * py + u->cy_inv;
+  return BSO_FMA(u->fy_inv, py, u->cy_inv);
+}
 static inline bso_f3 bso_unproject(const bso_unprojector* u, int x, int y, float depth) {   /* BS/surfel_projection.cuh:110-114 */
   return bso_make3(depth * bso_unproj_nx(u, (float)x), depth * bso_unproj_ny(u, (float)y), depth);
 }
@@ -106,8 +141,13 @@ static inline bso_f2 bso_project(float fx, float fy, float cx, float cy, bso_f3 
   /* The reference writes p.x / p.z and p.y / p.z and builds with -use_fast_math (BS/CMakeLists.txt:67), under which
      nvcc evaluates a / b as a * rcp(b).  The restatement takes that shape with a correctly rounded reciprocal, so
      that CPU and GPU agree to the last bit at one division per projection. */
-  const float inv_z = 1.0f / p.z;
   bso_f2 r;
+  if (BSO_LITERAL) {
+    r.x = fx * (p.x / p.z) + cx;
+    r.y = fy * (p.y / p.z) + cy;
+    return r;
+  }
+  const float inv_z = 1.0f / p.z;
   r.x = BSO_FMA(fx, p.x * inv_z, cx);
   r.y = BSO_FMA(fy, p.y * inv_z, cy);
   return r;
@@ -153,6 +193,7 @@ static inline float bso_expf(float x) {
 /* ---- BS/util.cuh:46-53 ------------------------------------------------------- */
 static inline float bso_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
+  if (BSO_LITERAL) return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
   return 1.f / (inv_depth + cfactor * bso_expf(-a * inv_depth));
 }
 
@@ -169,7 +210,8 @@ static inline bso_f3 bso_u16_to_image_space_normal(uint16_t value) {            
   bso_f3 r;
   r.x = bso_s8_to_small_float((int8_t)(value & 0x00ff));
   r.y = bso_s8_to_small_float((int8_t)((value & 0xff00) >> 8));
-  r.z = BSO_FMA(-r.y, r.y, BSO_FMA(-r.x, r.x, 1.0f));
+  if (BSO_LITERAL) r.z = 1 - r.x * r.x - r.y * r.y;                                         /* :126 */
+  else r.z = BSO_FMA(-r.y, r.y, BSO_FMA(-r.x, r.x, 1.0f));
   r.z = -sqrtf((r.z > 0.f) ? r.z : 0.f);
   return r;
 }
@@ -240,11 +282,13 @@ static inline float bso_huber_weight(float r, float k) {
 #define BSO_COS_NORMAL_COMPAT 0.76604f         /* BS/kernels.cuh:58 */
 
 static inline float bso_depth_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {      /* :81-83 */
+  if (BSO_LITERAL) return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth)) / baseline_fx;
   /* ".../ baseline_fx" in the reference; same -use_fast_math shape as bso_project: times the rounded reciprocal */
   const float inv_baseline_fx = 1.0f / baseline_fx;
   return (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(BSO_FMA(n.x, nx, BSO_FMA(n.y, ny, n.z))) * (depth * depth)) * inv_baseline_fx;
 }
 static inline float bso_depth_inv_stddev(float nx, float ny, float depth, bso_f3 n, float baseline_fx) {  /* :86-88 */
+  if (BSO_LITERAL) return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(n.x * nx + n.y * ny + n.z) * (depth * depth));
   return baseline_fx / (BSO_DEPTH_UNCERTAINTY_FACTOR * fabsf(BSO_FMA(n.x, nx, BSO_FMA(n.y, ny, n.z))) * (depth * depth));
 }
 static inline float bso_depth_weight(float r) { return BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_weight(r, 1.f * BSO_DEPTH_TUKEY); }           /* :91-93 */

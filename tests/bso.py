@@ -89,6 +89,9 @@ def lib():
                                                           _BUF, C.c_int, f64p, f64p, u32p]),
         "bso_compute_cost_and_residual_count_from_images": (None, [C.c_int, C.c_int, _CAM, _CAM, C.c_float, C.c_float, _BUF, _BUF, _BUF, P(abi.Mat3x4),
                                                                    _BUF, _BUF, _BUF, C.c_int, u32p, f64p]),
+        "bso_set_literal_mode": (None, [C.c_int]),
+        "bso_get_literal_mode": (C.c_int, []),
+        "bso_association_margins": (None, [_CAM, _DP, _KFS, C.c_uint32, _BUF, f64p]),
         "bso_bench_pose_pass": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, C.c_int, f32p, u32p, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -100,6 +103,16 @@ def lib():
 
 
 # ----------------------------------------------------------------------------- helpers
+
+class literal_mode:
+    """with bso.literal_mode(): the oracle evaluates the reference's expressions literally (oracle/bso_math.h)."""
+
+    def __enter__(self):
+        lib().bso_set_literal_mode(1)
+
+    def __exit__(self, *exc):
+        lib().bso_set_literal_mode(0)
+
 
 def np_buffer2d(arr):
     """bslam_buffer2d over a C-contiguous 2-D (or [h, w, 4] uint8) numpy array."""
@@ -337,6 +350,13 @@ class HostScene:
         dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
         lib().bso_association(C.byref(self.depth_camera), C.byref(dp), C.byref(v), self.surfels_size, C.byref(sb),
                               out.ctypes.data_as(P(C.c_uint32)))
+        return out[:self.surfels_size]
+
+    def association_margins(self, kf):
+        out = np.zeros((max(1, self.surfels_size), 5), np.float64)
+        dp, v, sb = self.depth_params(), kf.view(), self.surfel_buf()
+        lib().bso_association_margins(C.byref(self.depth_camera), C.byref(dp), C.byref(v), self.surfels_size, C.byref(sb),
+                                      out.ctypes.data_as(P(C.c_double)))
         return out[:self.surfels_size]
 
     def accumulate_pose(self, kf, frame_T_global=None, per_surfel=False, use_depth=None, use_desc=None):

@@ -277,8 +277,22 @@ def synthetic_scene(num_keyframes, seed=0xBAD51A4, width=W, height=H, cell=4, ma
     return scene
 
 
+def intrinsics_test_camera(width=W, height=H):
+    """True camera of the two intrinsics tests: {0.5h, 0.45h, 0.5w - 0.5, 0.5h - 0.5}
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:378, ..._photometric_residual.cc:112)."""
+    return bso.make_camera(0.5 * height, 0.45 * height, 0.5 * width - 0.5, 0.5 * height - 0.5, width, height)
+
+
+def distorted_camera(cam, scale=1.0):
+    """Start estimate of the intrinsics tests: the true camera + (+0.5, -0.6, +1.23, -2.17) px
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:416, ..._photometric_residual.cc:150); `scale` shrinks the
+    offsets with the image for the reduced-size CPU runs."""
+    return bso.make_camera(cam.fx + 0.5 * scale, cam.fy - 0.6 * scale, cam.cx + 1.23 * scale, cam.cy - 2.17 * scale, cam.width, cam.height)
+
+
 def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False,
-                    photometric=False, distortion=None, create_surfels=True):
+                    photometric=False, distortion=None, create_surfels=True, camera=None, filter_new_surfels=False,
+                    min_observation_count=2):
     """Scene of {Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual
     (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-560): 20 random planes rendered
     from `num_keyframes` poses global_T_0 * exp(xi) (:286-296), undistorted depth, cell size 2; surfels
@@ -289,9 +303,13 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
     the colour is a world-space sinusoid texture (:50-53), descriptor residuals only.
     distortion=(a, cfactor) distorts the rendered depth like TestDepthDeformationOptimizationWithGeometricResidual
     (:111-125: the inverse of the depth deformation model through the Lambert W function); create_surfels=False
-    leaves surfel creation to the BA under test (do_surfel_updates)."""
+    leaves surfel creation to the BA under test (do_surfel_updates).
+    camera: the true camera -- intrinsics_test_camera() (fy = 0.45 h) for the two intrinsics tests, the default
+    reference_test_camera() (fy = 0.5 h) for the depth-deformation test (:187).  filter_new_surfels=True creates the surfels
+    like the tests do (CreateSurfelsForKeyframe(stream, true, keyframe), :516 / :217, after ALL keyframes were added, so every
+    keyframe's co-visibility list is complete) with the constructor's min_observation_count of 2."""
     rng = np.random.default_rng(seed)
-    cam = reference_test_camera(width, height)
+    cam = camera or reference_test_camera(width, height)
     raw_to_float_depth = np.float32(1.0 / 1000)
     scene = bso.HostScene(cam, cam, float(raw_to_float_depth), 40.0, cell, max_surfels,
                           use_depth_residuals=not photometric, use_descriptor_residuals=use_descriptor_residuals or photometric)
@@ -333,6 +351,9 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
             col = np.stack([chan(g[..., 0], g[..., 1]), chan(g[..., 1], g[..., 2]), chan(g[..., 2], g[..., 0])], axis=-1)
             rgb = np.where((best > 0)[..., None], col, 0).astype(np.uint8)
         kf = scene.add_keyframe_from_images(depth, rgb, T)
-        if create_surfels:
+        if create_surfels and not filter_new_surfels:
             scene.create_surfels_for_keyframe(kf)
+    if create_surfels and filter_new_surfels:
+        for kf in scene.keyframes:
+            scene.create_surfels_for_keyframe_ex(kf, True, min_observation_count, [o for o in scene.keyframes if o is not kf])
     return scene

@@ -208,10 +208,9 @@ def test_intrinsics_step_matches_oracle(oracle):
     """bslam_optimize_intrinsics vs the oracle's OptimizeIntrinsicsCUDA restatement, one step from a
     distorted depth camera with non-zero a / cfactor (so that every Jacobian column is exercised)."""
     from tests import gpu_util
-    from tests.test_oracle_known_answers import distorted_camera
-    scene = scenes.intrinsics_scene(4, seed=3, width=640, height=480, cell=4, max_surfels=200000)
-    true = scene.depth_camera
-    scene.depth_camera = distorted_camera(true, 0.3)
+    true = scenes.intrinsics_test_camera()
+    scene = scenes.intrinsics_scene(4, seed=3, width=640, height=480, cell=4, max_surfels=200000, camera=true)
+    scene.depth_camera = scenes.distorted_camera(true, 8.0)
     scene.a = 0.01
     scene.cfactor[:, :] = np.random.default_rng(0).uniform(-0.002, 0.002, scene.cfactor.shape).astype(np.float32)
     hip = gpu_util.Hip(scene.to_device())
@@ -231,17 +230,33 @@ def test_intrinsics_step_matches_oracle(oracle):
     assert np.abs(scene.cfactor).max() > 1e-4
 
 
+def intrinsics_test_ba(scene):
+    """DirectBA as the two intrinsics tests construct it (merge factor 0.8, observation counts 2 / 2 / 2,
+    BS/test/test_intrinsics_optimization_geometric_residual.cc:421-436), keyframes added, then the surfels created from every
+    keyframe with the observation filter while the cameras are still the true ones (:515-517)."""
+    from badslam_amd.direct_ba import DirectBA
+    ba = DirectBA(scene.max_surfels, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, 0.8, 2, 2, 2,
+                  scene.color_camera, scene.depth_camera, 0, scene.use_depth_residuals, scene.use_descriptor_residuals)
+    ba.set_options(texture_mode=scene.tex_mode, pcg_gauge_keyframe=0)
+    for kf in scene.keyframes:
+        ba.AddKeyframe(kf.id, max(kf.min_depth, 1e-3), max(kf.max_depth, 1e-2), kf.depth, kf.normals, kf.radius, kf.color, kf.global_T_frame)
+    for kf in scene.keyframes:
+        ba.CreateSurfelsForKeyframe(True, kf.id)
+    return ba
+
+
 @pytest.mark.parametrize("use_pcg", [False, True])
 def test_intrinsics_optimization_with_geometric_residual(oracle, use_pcg):
-    """{Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual at full size
-    (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-557): 36 keyframes of 20 planes,
-    depth camera off by (+0.5, -10 % - 0.6, +1.23, -2.17) px, 100 BA calls that only optimise the
-    depth intrinsics; bar 1e-3 px (:539-542)."""
-    from tests.test_oracle_known_answers import distorted_camera
-    scene = scenes.intrinsics_scene(36, seed=0, cell=2, max_surfels=1000 * 1000)
-    true = scene.depth_camera
-    ba = make_ba(scene, pcg_gauge_keyframe=0)
-    d = distorted_camera(true, 1.0)
+    """{Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual exactly as the reference runs it
+    (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-553): true camera {0.5h, 0.45h, 0.5w - 0.5, 0.5h - 0.5} (:378),
+    36 keyframes of 20 planes, filtered surfel creation with the true camera, depth camera then set to true + (+0.5, -0.6,
+    +1.23, -2.17) px (:416, :518), 100 x BundleAdjustment(depth intrinsics only, no surfel updates, min 1 / max 10, first call
+    without increase_ba_iteration_count); bar 1e-3 px on fx, fy, cx, cy (:539-542)."""
+    true = scenes.intrinsics_test_camera()
+    scene = scenes.intrinsics_scene(36, seed=0, cell=2, max_surfels=1000 * 1000, camera=true, create_surfels=False)
+    ba = intrinsics_test_ba(scene)
+    assert ba.surfels_size() > 500000
+    d = scenes.distorted_camera(true)
     ba.set_intrinsics(None, [d.fx, d.fy, d.cx, d.cy], 0.0)
     for i in range(100):
         ba.BundleAdjustment(True, False, False, False, False, 1, 10, use_pcg, 0, len(scene.keyframes) - 1, i != 0)
@@ -252,42 +267,36 @@ def test_intrinsics_optimization_with_geometric_residual(oracle, use_pcg):
 
 @pytest.mark.parametrize("use_pcg", [False, True])
 def test_intrinsics_optimization_with_photometric_residual(oracle, use_pcg):
-    """{Alternating,PCG}IntrinsicsOptimizationWithPhotometricResidual
-    (BS/test/test_intrinsics_optimization_photometric_residual.cc:60-215): 12 keyframes, descriptor
-    residuals only, colour camera off by (+0.5, -10 % - 0.6, +1.23, -2.17) px; bars 0.03 px (fx, fy) and
-    0.15 px (cx, cy) (:203-206).
-
-    The reference issues 10 BA calls of one step each (min_iterations 1 and !optimize_poses end the
-    loop after the first iteration, BS/direct_ba_alternating.cc:693-700).  The restated Gauss-Newton
-    step (oracle and HIP agree on its trajectory, checked below) needs about 40 steps from a 24 px
-    focal-length error, so the bars are checked after 10 calls of up to 10 steps; whether the reference
-    itself meets them within 10 steps cannot be checked here (iteration count: parity unpinned)."""
-    from tests.test_oracle_known_answers import distorted_camera
-    scene = scenes.intrinsics_scene(12, seed=0, cell=2, max_surfels=1000 * 1000, photometric=True)
-    true = scene.color_camera
-    d = distorted_camera(true, 1.0)
-    if not use_pcg:
-        # the reference's schedule: 10 x 1 step, compared with the same 10 steps of the oracle (scheme-end
-        # deletion / radius update off: the oracle loop restates the intrinsics step only)
-        ba = make_ba(scene, pcg_gauge_keyframe=0, scheme_end_tasks=False)
-        ba.set_intrinsics([d.fx, d.fy, d.cx, d.cy], None, 0.0)
-        for i in range(10):
-            ba.BundleAdjustment(False, True, False, False, False, 1, 10, False, 0, len(scene.keyframes) - 1, i != 0)
-        cc, _, _ = ba.intrinsics()
-        true_cam = scene.color_camera
-        scene.color_camera = d
-        for i in range(10):
-            scene.optimize_intrinsics(False, True)
-        oc = scene.color_camera
-        scene.color_camera = true_cam
-        assert np.allclose(cc, [oc.fx, oc.fy, oc.cx, oc.cy], rtol=2e-4), (cc, oc.fx, oc.fy, oc.cx, oc.cy)
-    ba = make_ba(scene, pcg_gauge_keyframe=0)
+    """{Alternating,PCG}IntrinsicsOptimizationWithPhotometricResidual exactly as the reference runs it
+    (BS/test/test_intrinsics_optimization_photometric_residual.cc:104-265): true camera {0.5h, 0.45h, ...} (:112), 12 keyframes,
+    descriptor residuals only, filtered surfel creation with the true camera (:216-218), colour camera then set to true +
+    (+0.5, -0.6, +1.23, -2.17) px (:150, :219), 10 x BundleAdjustment(colour intrinsics only, do_surfel_updates, min 1 / max 10)
+    -- 10 single steps, since without pose optimisation the loop ends after min_iterations (BS/direct_ba_alternating.cc:693-700) --
+    bars 0.03 px (fx, fy) and 0.15 px (cx, cy) (:262-265)."""
+    true = scenes.intrinsics_test_camera()
+    scene = scenes.intrinsics_scene(12, seed=0, cell=2, max_surfels=1000 * 1000, photometric=True, camera=true, create_surfels=False)
+    ba = intrinsics_test_ba(scene)
+    assert ba.surfels_size() > 300000
+    d = scenes.distorted_camera(true)
     ba.set_intrinsics([d.fx, d.fy, d.cx, d.cy], None, 0.0)
+    trace = []
     for i in range(10):
-        ba.BundleAdjustment(False, True, False, False, False, 10, 10, use_pcg, 0, len(scene.keyframes) - 1, True)
-    cc, _, _ = ba.intrinsics()
+        its, _ = ba.BundleAdjustment(False, True, True, False, False, 1, 10, use_pcg, 0, len(scene.keyframes) - 1, i != 0)
+        assert its == 1
+        trace.append(ba.intrinsics()[0].copy())
+    cc = trace[-1]
     err = np.abs(cc - np.array([true.fx, true.fy, true.cx, true.cy], np.float32))
     assert err[0] < 0.03 and err[1] < 0.03 and err[2] < 0.15 and err[3] < 0.15, err
+    if not use_pcg:
+        # the same schedule on the oracle (tests/oracle_ba.py), step by step: the two trajectories agree far below the bars
+        from tests import oracle_ba
+        oscene = scenes.intrinsics_scene(12, seed=0, cell=2, max_surfels=1000 * 1000, photometric=True, camera=true, filter_new_surfels=True)
+        oscene.color_camera = d
+        oba = oracle_ba.OracleAlternatingBA(oscene)
+        for i in range(10):
+            oba.bundle_adjustment(False, True, True, False, 1, i != 0)
+            oc = oscene.color_camera
+            assert np.abs(trace[i] - np.array([oc.fx, oc.fy, oc.cx, oc.cy], np.float32)).max() < 2e-3, (i, trace[i], oc.fx, oc.fy, oc.cx, oc.cy)
 
 
 def test_save_and_load_calibration_through_direct_ba(oracle, tmp_path):

@@ -8,16 +8,15 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import bso, scenes                                   # noqa: E402
-from tests.test_gpu_direct_ba import make_ba                    # noqa: E402
-from tests.test_oracle_known_answers import distorted_camera    # noqa: E402
+from tests.test_gpu_direct_ba import intrinsics_test_ba         # noqa: E402
 
 bso.build_oracle()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for rep in range(n):
-    scene = scenes.intrinsics_scene(36, seed=0, cell=2, max_surfels=1000 * 1000)
-    true = scene.depth_camera
-    ba = make_ba(scene, pcg_gauge_keyframe=0)
-    d = distorted_camera(true, 1.0)
+    true = scenes.intrinsics_test_camera()
+    scene = scenes.intrinsics_scene(36, seed=0, cell=2, max_surfels=1000 * 1000, camera=true, create_surfels=False)
+    ba = intrinsics_test_ba(scene)
+    d = scenes.distorted_camera(true)
     ba.set_intrinsics(None, [d.fx, d.fy, d.cx, d.cy], 0.0)
     for i in range(100):
         ba.BundleAdjustment(True, False, False, False, False, 1, 10, True, 0, len(scene.keyframes) - 1, i != 0)
