@@ -13,13 +13,25 @@
 
 #define K_A_ROWS 5
 
+/* Summation of the GLOBAL blocks (A, b1, colour H, b): 0 (default) = fp32 additions in (keyframe, surfel) order, the
+ * order a serialised run of the reference's atomics would give; 1 = the same fp32 terms added in float64 and rounded once
+ * (the "truth" a tree- or atomics-ordered fp32 sum is compared with: a serial fp32 sum of ~4e6 terms is itself only good to
+ * ~1e-3 relative, and the 4x4 / 5x5 solves amplify that). */
+static int g_sum64 = 0;
+void bso_set_intrinsics_sum64(int enable) { g_sum64 = enable != 0; }
+
+typedef struct { float f[15]; double d[15]; } acc15;
+static void acc_add(acc15* a, int i, float v) { a->f[i] += v; a->d[i] += (double)v; }
+static float acc_get(const acc15* a, int i) { return g_sum64 ? (float)a->d[i] : a->f[i]; }
+static double acc_getd(const acc15* a, int i) { return a->d[i]; }
+
 /* AccumulateGaussNewtonHAndB<size> BS/gauss_newton.cuh:47-95 for a generic size */
-static void accumulate_n(int n, float raw, float w, const float* J, float* H, float* b) {
+static void accumulate_n(int n, float raw, float w, const float* J, acc15* H, acc15* b) {
   int idx = 0;
   for (int row = 0; row < n; ++row)
-    for (int col = row; col < n; ++col) { H[idx] += w * J[row] * J[col]; ++idx; }
+    for (int col = row; col < n; ++col) { acc_add(H, idx, w * J[row] * J[col]); ++idx; }
   const float wr = w * raw;
-  for (int i = 0; i < n; ++i) b[i] += wr * J[i];
+  for (int i = 0; i < n; ++i) acc_add(b, i, wr * J[i]);
 }
 
 void bso_optimize_intrinsics(
@@ -33,8 +45,7 @@ void bso_optimize_intrinsics(
   const bso_depth_to_color d2c = bso_make_depth_to_color(depth_camera, color_camera);
   const int cw = dp->cfactor_buffer.width;
   const int cells = ((depth_camera->width - 1) / dp->sparse_surfel_cell_size + 1) * ((depth_camera->height - 1) / dp->sparse_surfel_cell_size + 1);
-  float A[15] = {0}, b1[K_A_ROWS] = {0};
-  float color_H[10] = {0}, color_b[4] = {0};
+  acc15 accA = {{0}, {0}}, accb1 = {{0}, {0}}, acc_color_H = {{0}, {0}}, acc_color_b = {{0}, {0}};
   float* B = (float*)calloc((size_t)K_A_ROWS * cells, sizeof(float));
   float* D = (float*)calloc((size_t)cells, sizeof(float));
   float* b2 = (float*)calloc((size_t)cells, sizeof(float));
@@ -91,21 +102,27 @@ void bso_optimize_intrinsics(
       }
       if (optimize_depth_intrinsics && cell >= 0) {                 /* :170-196 */
         const float w = bso_depth_weight(raw_depth);
-        accumulate_n(K_A_ROWS, raw_depth, w, dj, A, b1);
+        accumulate_n(K_A_ROWS, raw_depth, w, dj, &accA, &accb1);
         for (int q = 0; q < K_A_ROWS; ++q) B[(size_t)q * cells + cell] += w * dj[q] * dj[K_A_ROWS];
         D[cell] += w * dj[K_A_ROWS] * dj[K_A_ROWS];
         b2[cell] += w * raw_depth * dj[K_A_ROWS];
         obs[cell] += 1;
       }
       if (optimize_color_intrinsics) {                              /* :198-216: "valid" = residual != 0 */
-        if (r1 != 0) accumulate_n(4, r1, bso_desc_weight(r1), j1, color_H, color_b);
-        if (r2 != 0) accumulate_n(4, r2, bso_desc_weight(r2), j2, color_H, color_b);
+        if (r1 != 0) accumulate_n(4, r1, bso_desc_weight(r1), j1, &acc_color_H, &acc_color_b);
+        if (r2 != 0) accumulate_n(4, r2, bso_desc_weight(r2), j2, &acc_color_H, &acc_color_b);
       }
     }
   }
 
+  float A[15], b1[K_A_ROWS], color_H[10], color_b[4];
+  for (int i = 0; i < 15; ++i) A[i] = acc_get(&accA, i);
+  for (int i = 0; i < K_A_ROWS; ++i) b1[i] = acc_get(&accb1, i);
+  for (int i = 0; i < 10; ++i) color_H[i] = acc_get(&acc_color_H, i);
+  for (int i = 0; i < 4; ++i) color_b[i] = acc_get(&acc_color_b, i);
   if (optimize_depth_intrinsics) {
     /* ComputeIntrinsicsIntermediateMatricesCUDAKernel :265-340 */
+    double A64[15] = {0}, b164[K_A_ROWS] = {0};   /* sum64 mode: the Schur corrections summed in float64, applied once */
     for (int p = 0; p < cells; ++p) {
       const float D_inverse = 1.0f / D[p];
       if (!(D_inverse < 1e12f)) { D[p] = NAN; continue; }
@@ -113,9 +130,20 @@ void bso_optimize_intrinsics(
       D[p] = D_inv_b2;
       int idx = 0;
       for (int row = 0; row < K_A_ROWS; ++row)
-        for (int col = row; col < K_A_ROWS; ++col) { A[idx] += -1.f * (B[(size_t)row * cells + p] * D_inverse * B[(size_t)col * cells + p]); ++idx; }
-      for (int row = 0; row < K_A_ROWS; ++row) b1[row] += -1.f * (B[(size_t)row * cells + p] * D_inv_b2);
+        for (int col = row; col < K_A_ROWS; ++col) {
+          const float v = -1.f * (B[(size_t)row * cells + p] * D_inverse * B[(size_t)col * cells + p]);
+          if (g_sum64) A64[idx] += (double)v; else A[idx] += v;
+          ++idx;
+        }
+      for (int row = 0; row < K_A_ROWS; ++row) {
+        const float v = -1.f * (B[(size_t)row * cells + p] * D_inv_b2);
+        if (g_sum64) b164[row] += (double)v; else b1[row] += v;
+      }
       for (int row = 0; row < K_A_ROWS; ++row) B[(size_t)row * cells + p] = D_inverse * B[(size_t)row * cells + p];
+    }
+    if (g_sum64) {
+      for (int i = 0; i < 15; ++i) A[i] = (float)(acc_getd(&accA, i) + A64[i]);
+      for (int i = 0; i < K_A_ROWS; ++i) b1[i] = (float)(acc_getd(&accb1, i) + b164[i]);
     }
     /* host solve BS/kernel_opt_intrinsics.cc:129-186 */
     const float kAPriorWeight = 10;

@@ -48,8 +48,9 @@ class OracleAlternatingBA:
     oracle's.  With optimize_poses = false the loop ends after min_iterations iterations (:693-700) and no keyframe ever
     leaves the kActive state, so one call is `min_iterations` iteration bodies."""
 
-    def __init__(self, scene, merge_dist_factor=0.8, min_observation_count=2):
+    def __init__(self, scene, merge_dist_factor=0.8, min_observation_count=2, covisibility=None):
         self.scene = scene
+        self.covisibility = covisibility           # {keyframe id: [ids]} or None = every other keyframe
         self.merge_dist_factor = merge_dist_factor
         self.min_obs = min_observation_count       # the tests pass 2 for all three bootstrapping levels
         self.ba_iteration_count = 0
@@ -58,6 +59,8 @@ class OracleAlternatingBA:
         self.surfel_count = scene.surfels_size
 
     def covis(self, kf):
+        if self.covisibility is not None:
+            return [self.scene.keyframes[j] for j in self.covisibility[kf.id]]
         return [o for o in self.scene.keyframes if o is not kf]
 
     def scheme_end_tasks(self, do_surfel_updates):                      # BS/direct_ba.cc:566-653

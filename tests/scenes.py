@@ -292,7 +292,7 @@ def distorted_camera(cam, scale=1.0):
 
 def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfels=1000 * 1000, use_descriptor_residuals=False,
                     photometric=False, distortion=None, create_surfels=True, camera=None, filter_new_surfels=False,
-                    min_observation_count=2):
+                    min_observation_count=2, covisibility=None):
     """Scene of {Alternating,PCG}IntrinsicsOptimizationWithGeometricResidual
     (BS/test/test_intrinsics_optimization_geometric_residual.cc:371-560): 20 random planes rendered
     from `num_keyframes` poses global_T_0 * exp(xi) (:286-296), undistorted depth, cell size 2; surfels
@@ -307,7 +307,8 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
     camera: the true camera -- intrinsics_test_camera() (fy = 0.45 h) for the two intrinsics tests, the default
     reference_test_camera() (fy = 0.5 h) for the depth-deformation test (:187).  filter_new_surfels=True creates the surfels
     like the tests do (CreateSurfelsForKeyframe(stream, true, keyframe), :516 / :217, after ALL keyframes were added, so every
-    keyframe's co-visibility list is complete) with the constructor's min_observation_count of 2."""
+    keyframe's co-visibility list is complete) with the constructor's min_observation_count of 2; covisibility = {keyframe id:
+    [ids]} (e.g. the host class's frustum-intersection lists, BS/direct_ba.cc:231-249), default: every other keyframe."""
     rng = np.random.default_rng(seed)
     cam = camera or reference_test_camera(width, height)
     raw_to_float_depth = np.float32(1.0 / 1000)
@@ -355,5 +356,6 @@ def intrinsics_scene(num_keyframes, seed=0, width=W, height=H, cell=2, max_surfe
             scene.create_surfels_for_keyframe(kf)
     if create_surfels and filter_new_surfels:
         for kf in scene.keyframes:
-            scene.create_surfels_for_keyframe_ex(kf, True, min_observation_count, [o for o in scene.keyframes if o is not kf])
+            others = [o for o in scene.keyframes if o is not kf] if covisibility is None else [scene.keyframes[j] for j in covisibility[kf.id]]
+            scene.create_surfels_for_keyframe_ex(kf, True, min_observation_count, others)
     return scene
