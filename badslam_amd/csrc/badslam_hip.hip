@@ -471,6 +471,26 @@ int bslam_debug_decode_normals(bslam_context* ctx, void* stream_, float* out_xyz
   return BSLAM_OK;
 }
 
+int bslam_debug_jacobians(bslam_context* ctx, void* stream_, int kind, int count, const float* in, float* out) {
+  hipStream_t stream = (hipStream_t)stream_;
+  static const int kIn[7] = {10, 1, 21, 11, 14, 8, 10}, kOut[7] = {7, 1, 7, 9, 1, 4, 7};
+  if (!ctx || !in || !out) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if (kind < 0 || kind > 6) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown probe kind %d", kind);
+  if (count <= 0) return BSLAM_OK;
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t in_bytes = (size_t)count * kIn[kind] * sizeof(float), out_bytes = (size_t)count * kOut[kind] * sizeof(float);
+  int rc = ctx->coeffs.reserve(in_bytes + out_bytes);
+  if (rc) return rc;
+  float* d_in = (float*)ctx->coeffs.ptr;
+  float* d_out = (float*)((uint8_t*)ctx->coeffs.ptr + in_bytes);
+  BSLAM_HIP_TRY(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(jacobian_probe_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, kind, count, kIn[kind], kOut[kind], (const float*)d_in, d_out);
+  BSLAM_HIP_TRY(hipGetLastError());
+  BSLAM_HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  return BSLAM_OK;
+}
+
 int bslam_debug_count_pairs(
     bslam_context* ctx, void* stream_, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
     int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size, const bslam_buffer2d* surfels,

@@ -505,28 +505,53 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   return true;
 }
 
-// Depth residual and its pose Jacobian (BS/kernel_opt_pose.cu:45-94, BS/cost_function.cuh:56-88).
+// ---------------------------------------------------------------------------------------------
+// Residuals and Jacobians: ONE definition per formula, used by every kernel (pose, geometry, PCG, intrinsics,
+// odometry) and checked point by point against the reference's own symbolic derivation
+// (applications/badslam/scripts/jacobians_derivation.py -> tests/golden/jacobian_golden.npz) through
+// bslam_debug_jacobians (tests/test_gpu_jacobians.py); the CPU checker used by the tests holds the same set.
+// ---------------------------------------------------------------------------------------------
+// Depth residual (BS/cost_function.cuh:56-68): n_local = surfel normal in the frame, lu = unprojected pixel,
+// ls = surfel position in the frame.
+__device__ __forceinline__ float depth_residual(float inv_stddev, f3 n_local, f3 lu, f3 ls) { return inv_stddev * dot(n_local, sub3(lu, ls)); }
+// ... and its Jacobian wrt. the pose delta (BS/kernel_opt_pose.cu:45-94)
+__device__ __forceinline__ void depth_pose_jacobian(float inv_stddev, f3 n_local, f3 lu, float* J) {
+  J[0] = inv_stddev * n_local.x;
+  J[1] = inv_stddev * n_local.y;
+  J[2] = inv_stddev * n_local.z;
+  J[3] = inv_stddev * (-n_local.y * lu.z + n_local.z * lu.y);
+  J[4] = inv_stddev * (n_local.x * lu.z - n_local.z * lu.x);
+  J[5] = inv_stddev * (-n_local.x * lu.y + n_local.y * lu.x);
+}
+// The pose kernel's form of the two: past the association test nothing feeds an integer output any more, so residual and
+// Jacobian may use fused multiply-adds (as the reference's nvcc build does by default); the predicate path stays unfused.
+__device__ __forceinline__ void depth_residual_and_pose_jacobian_fused(float inv_stddev, f3 n_local, f3 lu, f3 ls, float* raw, float* J) {
+#pragma clang fp contract(fast)
+  const f3 dl = mk3(lu.x - ls.x, lu.y - ls.y, lu.z - ls.z);
+  *raw = inv_stddev * (n_local.x * dl.x + n_local.y * dl.y + n_local.z * dl.z);
+  J[0] = inv_stddev * n_local.x;
+  J[1] = inv_stddev * n_local.y;
+  J[2] = inv_stddev * n_local.z;
+  J[3] = inv_stddev * (-n_local.y * lu.z + n_local.z * lu.y);
+  J[4] = inv_stddev * (n_local.x * lu.z - n_local.z * lu.x);
+  J[5] = inv_stddev * (-n_local.x * lu.y + n_local.y * lu.x);
+}
+__device__ __forceinline__ f3 pixel_unprojection(const Proj& r) {   // unproject(c, r.px, r.py, r.depth) from the cached nx, ny
+#pragma clang fp contract(fast)
+  return mk3(r.depth * r.nx, r.depth * r.ny, r.depth);
+}
 __device__ __forceinline__ void depth_residual_and_jacobian(const CamConsts& c, const Proj& r, float* raw, float* J) {
   const float inv_stddev = depth_inv_stddev(r.nx, r.ny, r.depth, r.n_local, c.baseline_fx);
-  {
-    // Past the association test nothing feeds an integer output any more: residual and Jacobian may use fused
-    // multiply-adds (as the reference's nvcc build does by default); the predicate path stays unfused.
-#pragma clang fp contract(fast)
-    const f3 lu = mk3(r.depth * r.nx, r.depth * r.ny, r.depth);
-    const f3 dl = mk3(lu.x - r.local.x, lu.y - r.local.y, lu.z - r.local.z);
-    *raw = inv_stddev * (r.n_local.x * dl.x + r.n_local.y * dl.y + r.n_local.z * dl.z);
-    J[0] = inv_stddev * r.n_local.x;
-    J[1] = inv_stddev * r.n_local.y;
-    J[2] = inv_stddev * r.n_local.z;
-    J[3] = inv_stddev * (-r.n_local.y * lu.z + r.n_local.z * lu.y);
-    J[4] = inv_stddev * (r.n_local.x * lu.z - r.n_local.z * lu.x);
-    J[5] = inv_stddev * (-r.n_local.x * lu.y + r.n_local.y * lu.x);
-  }
+  depth_residual_and_pose_jacobian_fused(inv_stddev, r.n_local, pixel_unprojection(r), r.local, raw, J);
 }
+// Depth residual wrt. a surfel move of t along its (unit) normal (BS/kernel_opt_geometry.cu:440, BS/kernel_pcg.cu:217).
+__device__ __forceinline__ float depth_position_jacobian(float inv_stddev) { return -inv_stddev; }
 
-// Pose Jacobian of one descriptor residual (BS/kernel_opt_pose.cu:122-141).
+// Descriptor residual wrt. the pose delta (BS/kernel_opt_pose.cu:122-141); gx, gy = image gradient of the residual times the
+// colour camera's fx, fy; ls = surfel position in the frame.  kExact: correctly rounded reciprocal (odometry, as the oracle).
+template <bool kExact = false>
 __device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 ls, float* J) {
-  const float inv_ls_z = rrcp(ls.z);
+  const float inv_ls_z = kExact ? 1.f / ls.z : rrcp(ls.z);
   const float ls_z_sq = ls.z * ls.z;
   const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
   J[0] = -gx * inv_ls_z;
@@ -536,6 +561,40 @@ __device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 
   J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
   J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
   J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+}
+// Descriptor residual wrt. a surfel move along its normal (BS/kernel_opt_geometry.cu:175-189, BS/kernel_pcg.cu:364-372):
+// rn = normal in the frame, ls = position in the frame; the gradient (gx, gy) is multiplied by (fx, fy) here (the PCG kernels
+// pass gradients that already carry the focal lengths and fx = fy = 1).
+__device__ __forceinline__ float descriptor_position_jacobian(float gx, float gy, float fx, float fy, f3 rn, f3 ls) {
+  const float term1 = -fx * (rn.x * ls.z - rn.z * ls.x);
+  const float term2 = -fy * (rn.y * ls.z - rn.z * ls.y);
+  const float term3 = rrcp(ls.z * ls.z);
+  return -(gx * term1 + gy * term2) * term3;
+}
+// Depth residual wrt. (fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor of the pixel's cell), dj[0..5]
+// (BS/kernel_opt_intrinsics.cu:82-118 = BS/kernel_pcg.cu:258-322).  m = frame_T_global, ln = normal in the frame.  Returns
+// corrected_inv_depth, on which the callers base their validity tests.
+__device__ __forceinline__ float depth_intrinsics_jacobian(float inv_stddev, float calibrated_depth, int px, int py, float nx, float ny, f3 n_global,
+                                                          const float* m, f3 ln, float cfactor, float a, float raw_inv_depth, float* dj) {
+  const float exp_inv_depth = det_expf(-a * raw_inv_depth);
+  const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+  const float dt = dot(mk3(nx, ny, 1), ln);
+  const float jac_base = inv_stddev * dt * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
+  dj[2] = inv_stddev * calibrated_depth * dot(n_global, mk3(m[0], m[1], m[2]));
+  dj[3] = inv_stddev * calibrated_depth * dot(n_global, mk3(m[4], m[5], m[6]));
+  dj[0] = (float)px * dj[2];
+  dj[1] = (float)py * dj[3];
+  dj[4] = cfactor * raw_inv_depth * jac_base;
+  dj[5] = -jac_base;
+  return corrected_inv_depth;
+}
+// Descriptor residual wrt. the colour camera's (fx, fy, cx, cy) (BS/kernel_opt_intrinsics.cu:141-149, BS/kernel_pcg.cu:462-509):
+// gx, gy = image gradient of the residual (no focal length), nx, ny = normalised image coordinates of the pixel.
+__device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, float nx, float ny, float* j) {
+  j[0] = gx * nx;
+  j[1] = gy * ny;
+  j[2] = gx;
+  j[3] = gy;
 }
 
 // ---------------------------------------------------------------------------------------------

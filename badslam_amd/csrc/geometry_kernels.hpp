@@ -126,6 +126,49 @@ __global__ __launch_bounds__(256) void decode_normals_kernel(float* __restrict__
   out[3 * code + 2] = n.z;
 }
 
+// bslam_debug_jacobians: the residual / Jacobian functions of device_math.hpp at given points (layouts: include/badslam_hip.h)
+__global__ __launch_bounds__(256) void jacobian_probe_kernel(int kind, int count, int in_width, int out_width, const float* __restrict__ in, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float* a = in + (size_t)i * in_width;
+  float* o = out + (size_t)i * out_width;
+  if (kind == 0 || kind == 6) {
+    const f3 nl = mk3(a[1], a[2], a[3]), lu = mk3(a[4], a[5], a[6]), ls = mk3(a[7], a[8], a[9]);
+    float raw, J[6];
+    if (kind == 0) { raw = depth_residual(a[0], nl, lu, ls); depth_pose_jacobian(a[0], nl, lu, J); }
+    else depth_residual_and_pose_jacobian_fused(a[0], nl, lu, ls, &raw, J);
+    o[0] = raw;
+    for (int k = 0; k < 6; ++k) o[1 + k] = J[k];
+  } else if (kind == 1) {
+    o[0] = depth_position_jacobian(a[0]);
+  } else if (kind == 2) {
+    const float m[12] = {a[9], a[10], a[11], 0, a[12], a[13], a[14], 0, 0, 0, 0, 0};
+    float dj[6];
+    o[0] = depth_intrinsics_jacobian(a[0], a[1], (int)a[2], (int)a[3], a[4], a[5], mk3(a[6], a[7], a[8]), m, mk3(a[15], a[16], a[17]), a[18], a[19], a[20], dj);
+    for (int k = 0; k < 6; ++k) o[1 + k] = dj[k];
+  } else {
+    const LumaQuad q{a[0], a[1], a[2], a[3]};
+    GradFootprint g;
+    g.ix = g.iy = 0; g.tx = a[4]; g.ty = a[5];
+    float dx, dy;
+    grad_filter(q, g, &dx, &dy);
+    if (kind == 3) {
+      float J[6];
+      o[0] = tex_filter(q, a[4], a[5]);
+      o[1] = dx * a[6];
+      o[2] = dy * a[7];
+      descriptor_pose_jacobian(o[1], o[2], mk3(a[8], a[9], a[10]), J);
+      for (int k = 0; k < 6; ++k) o[3 + k] = J[k];
+    } else if (kind == 4) {
+      o[0] = descriptor_position_jacobian(dx, dy, a[6], a[7], mk3(a[8], a[9], a[10]), mk3(a[11], a[12], a[13]));
+    } else {
+      float j[4];
+      color_intrinsics_jacobian(dx, dy, a[6], a[7], j);
+      for (int k = 0; k < 4; ++k) o[k] = j[k];
+    }
+  }
+}
+
 // Census: pairs passing z > 0 and bounds, and associated pairs (roofline accounting).
 __global__ __launch_bounds__(256) void count_pairs_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, SurfelRowsRW s,
                                                           unsigned long long* __restrict__ out) {
@@ -242,9 +285,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
       const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
-      const float dj = -inv_stddev;
+      const float dj = depth_position_jacobian(inv_stddev);
       const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-      const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+      const float raw = depth_residual(inv_stddev, p.n_local, lu, p.local);
       const float w = depth_weight(raw);
       const float wj = w * dj;
       H += wj * dj;
@@ -272,9 +315,9 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       const f3 rn = p.n_local;
       if (kDepth) {
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
-        const float dj = -inv_stddev;
+        const float dj = depth_position_jacobian(inv_stddev);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float raw = depth_residual(inv_stddev, rn, lu, p.local);
         const float w = depth_weight(raw);
         A0 += w * dj * dj;
         A6 += w * raw * dj;
@@ -285,11 +328,8 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
         project_tangent_points(tp1, tp2, kf.frame_T_global, c, &t1, &t2);
         float r1, rr2, gx1, gy1, gx2, gy2;
         descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-        const float term1 = -c.cfx * (rn.x * p.local.z - rn.z * p.local.x);
-        const float term2 = -c.cfy * (rn.y * p.local.z - rn.z * p.local.y);
-        const float term3 = rrcp(p.local.z * p.local.z);
-        const float jp1 = -(gx1 * term1 + gy1 * term2) * term3;
-        const float jp2 = -(gx2 * term1 + gy2 * term2) * term3;
+        const float jp1 = descriptor_position_jacobian(gx1, gy1, c.cfx, c.cfy, rn, p.local);
+        const float jp2 = descriptor_position_jacobian(gx2, gy2, c.cfx, c.cfy, rn, p.local);
         const float jd = -1.f;
         const float w1 = desc_weight(r1);
         const float wr1 = w1 * r1;
@@ -392,9 +432,9 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
       Proj p;
       if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
-      const float dj = -inv_stddev;
+      const float dj = depth_position_jacobian(inv_stddev);
       const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-      const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+      const float raw = depth_residual(inv_stddev, p.n_local, lu, p.local);
       const float w = depth_weight(raw);
       const float wj = w * dj;
       H[r] += wj * dj;
@@ -454,9 +494,9 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
         a3[r] += 1.f;
       } else {
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
-        const float dj = -inv_stddev;
+        const float dj = depth_position_jacobian(inv_stddev);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);
-        const float raw = inv_stddev * dot(p.n_local, sub3(lu, p.local));
+        const float raw = depth_residual(inv_stddev, p.n_local, lu, p.local);
         const float w = depth_weight(raw);
         const float wj = w * dj;
         a0[r] += wj * dj;

@@ -69,23 +69,14 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
         const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
         const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)p.raw_depth);
-        const float exp_inv_depth = det_expf(-c.a * raw_inv_depth);
-        const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+        const f3 ln = p.n_local;
+        const float inv_stddev = depth_inv_stddev(nx, ny, p.depth, ln, c.baseline_fx);
+        float dj[6];
+        const float corrected_inv_depth = depth_intrinsics_jacobian(inv_stddev, p.depth, p.px, p.py, nx, ny, gn[r], kf.frame_T_global.m, ln, cfactor, c.a,
+                                                                    raw_inv_depth, dj);
         if (fabsf(corrected_inv_depth) > 1e-4f) {
-          const f3 ln = p.n_local;
-          const float dt = dot(mk3(nx, ny, 1), ln);
-          const float inv_stddev = depth_inv_stddev(nx, ny, p.depth, ln, c.baseline_fx);
-          const float jac_base = inv_stddev * dt * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
-          const float* m = kf.frame_T_global.m;
-          float dj[6];
-          dj[2] = inv_stddev * p.depth * dot(gn[r], mk3(m[0], m[1], m[2]));
-          dj[3] = inv_stddev * p.depth * dot(gn[r], mk3(m[4], m[5], m[6]));
-          dj[0] = (float)p.px * dj[2];
-          dj[1] = (float)p.py * dj[3];
-          dj[4] = cfactor * raw_inv_depth * jac_base;
-          dj[5] = -jac_base;
           const f3 lu = mk3(p.depth * nx, p.depth * ny, p.depth);
-          const float raw = inv_stddev * dot(ln, sub3(lu, p.local));
+          const float raw = depth_residual(inv_stddev, ln, lu, p.local);
           const float w = depth_weight(raw);
           int idx = 0;
 #pragma unroll
@@ -111,8 +102,9 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
           tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
           float r1, rr2, gx1, gy1, gx2, gy2;
           descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-          const float j1[4] = {gx1 * nx, gy1 * ny, gx1, gy1};
-          const float j2[4] = {gx2 * nx, gy2 * ny, gx2, gy2};
+          float j1[4], j2[4];
+          color_intrinsics_jacobian(gx1, gy1, nx, ny, j1);
+          color_intrinsics_jacobian(gx2, gy2, nx, ny, j2);
           if (r1 != 0) {   // the reference uses "residual != 0" as the validity flag (:200, :208)
             const float w = desc_weight(r1);
             int idx = 20;

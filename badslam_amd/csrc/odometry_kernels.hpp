@@ -154,13 +154,8 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
     if (visible && kDepth) {
       const float inv_stddev = depth_inv_stddev(nx_of(c, (float)px), ny_of(c, (float)py), pixel_depth, n_local, c.baseline_fx);
       const f3 lu = unproject(c, px, py, pixel_depth);
-      raw_depth = inv_stddev * dot(n_local, sub3(lu, local));
-      Jd[0] = inv_stddev * n_local.x;
-      Jd[1] = inv_stddev * n_local.y;
-      Jd[2] = inv_stddev * n_local.z;
-      Jd[3] = inv_stddev * (-n_local.y * lu.z + n_local.z * lu.y);
-      Jd[4] = inv_stddev * (n_local.x * lu.z - n_local.z * lu.x);
-      Jd[5] = inv_stddev * (-n_local.x * lu.y + n_local.y * lu.x);
+      raw_depth = depth_residual(inv_stddev, n_local, lu, local);
+      depth_pose_jacobian(inv_stddev, n_local, lu, Jd);
     }
     if (visible && kDesc) {
       if (x < w - 1 && y < h - 1) {
@@ -188,12 +183,8 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
             gx1 *= c.cfx; gx2 *= c.cfx;
             gy1 *= c.cfy; gy2 *= c.cfy;
             // exact reciprocal here (ComputeRawDescriptorResidualAndJacobianWithFloatTexture BS/kernel_opt_pose.cu:168-190): odometry is not the hot path
-            const f3 ls = local;
-            const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
-            J1[0] = -gx1 * inv_z; J1[1] = -gy1 * inv_z; J1[2] = (ls.x * gx1 + ls.y * gy1) * inv_z_sq;
-            J1[3] = ((ls.y * ls.y + z_sq) * gy1 + xy * gx1) * inv_z_sq; J1[4] = -((ls.x * ls.x + z_sq) * gx1 + xy * gy1) * inv_z_sq; J1[5] = -(ls.x * gy1 - ls.y * gx1) * inv_z;
-            J2[0] = -gx2 * inv_z; J2[1] = -gy2 * inv_z; J2[2] = (ls.x * gx2 + ls.y * gy2) * inv_z_sq;
-            J2[3] = ((ls.y * ls.y + z_sq) * gy2 + xy * gx2) * inv_z_sq; J2[4] = -((ls.x * ls.x + z_sq) * gx2 + xy * gy2) * inv_z_sq; J2[5] = -(ls.x * gy2 - ls.y * gx2) * inv_z;
+            descriptor_pose_jacobian<true>(gx1, gy1, local, J1);
+            descriptor_pose_jacobian<true>(gx2, gy2, local, J2);
           }
         } else {
           visible = false;

@@ -82,19 +82,14 @@ __device__ __forceinline__ DepthIntrinsicsTerms depth_intrinsics_terms(const Cam
   const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
   const uint32_t measured = p.raw_depth;
   const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)measured);
-  const float exp_inv_depth = det_expf(-c.a * raw_inv_depth);
-  const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
-  t.valid = !(fabsf(corrected_inv_depth) < 1e-4f);
   const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
-  const float dt = dot(mk3(nx, ny, 1), p.n_local);
-  const float jac_base = inv_stddev * dt * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
-  const float* m = kf.frame_T_global.m;
-  t.d[2] = inv_stddev * p.depth * dot(gn, mk3(m[0], m[1], m[2]));
-  t.d[3] = inv_stddev * p.depth * dot(gn, mk3(m[4], m[5], m[6]));
-  t.d[0] = (float)p.px * t.d[2];
-  t.d[1] = (float)p.py * t.d[3];
-  t.d[4] = cfactor * raw_inv_depth * jac_base;
-  t.cf_jac = -jac_base;
+  float dj[6];
+  const float corrected_inv_depth = depth_intrinsics_jacobian(inv_stddev, p.depth, p.px, p.py, nx, ny, gn, kf.frame_T_global.m, p.n_local, cfactor, c.a,
+                                                              raw_inv_depth, dj);
+  t.valid = !(fabsf(corrected_inv_depth) < 1e-4f);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) t.d[j] = dj[j];
+  t.cf_jac = dj[5];
   t.cf_index = d0 + 5 + (uint32_t)sparse_px + (uint32_t)sparse_py * (uint32_t)c.cfactor_width;
   return t;
 }
@@ -168,17 +163,16 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       if (kDepth) {
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float raw = depth_residual(inv_stddev, rn, lu, p.local);
         const float weight = depth_weight(raw);
         if (P.optimize_geometry) {                               // :217-221
-          const float jp = -inv_stddev;
+          const float jp = depth_position_jacobian(inv_stddev);
           ar[r][0] -= jp * weight * raw;
           aM[r][0] += jp * weight * jp;
         }
         if (opt_pose) {                                          // :224-255
-          const float J[6] = {inv_stddev * rn.x, inv_stddev * rn.y, inv_stddev * rn.z,
-                              inv_stddev * (-rn.y * lu.z + rn.z * lu.y), inv_stddev * (rn.x * lu.z - rn.z * lu.x),
-                              inv_stddev * (-rn.x * lu.y + rn.y * lu.x)};
+          float J[6];
+          depth_pose_jacobian(inv_stddev, rn, lu, J);
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
             const float wj = weight * J[j];
@@ -211,11 +205,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         const DescTerms t = descriptor_terms(c, kf, gp[r], gn[r], r2[r], d1[r], d2[r], color_pxy);
         const f3 ls = p.local;
         if (P.optimize_geometry) {                               // :364-399
-          const float term1 = -(rn.x * ls.z - rn.z * ls.x);
-          const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-          const float term3 = rrcp(ls.z * ls.z);
-          const float jp1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
-          const float jp2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
+          const float jp1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);   // gx, gy already carry fx, fy
+          const float jp2 = descriptor_position_jacobian(t.gx2, t.gy2, 1.f, 1.f, rn, ls);
           ar[r][0] -= jp1 * t.w1 * t.r1 + jp2 * t.w2 * t.r2;
           aM[r][0] += jp1 * t.w1 * jp1 + jp2 * t.w2 * jp2;
           const float j11 = -1, j12 = 0, j21 = 0, j22 = -1;
@@ -424,19 +415,16 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
       if (kDepth) {
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-        const float raw = inv_stddev * dot(rn, sub3(lu, p.local));
+        const float raw = depth_residual(inv_stddev, rn, lu, p.local);
         const float weight = depth_weight(raw);
         float sum = 0;
         float gj = 0;
         float J[6] = {0, 0, 0, 0, 0, 0};
-        if (P.optimize_geometry) { gj = -inv_stddev; sum += gj * ps[r][0]; }
+        if (P.optimize_geometry) { gj = depth_position_jacobian(inv_stddev); sum += gj * ps[r][0]; }
         if (opt_pose) {
-          J[0] = inv_stddev * rn.x;                              sum += J[0] * pp[0];
-          J[1] = inv_stddev * rn.y;                              sum += J[1] * pp[1];
-          J[2] = inv_stddev * rn.z;                              sum += J[2] * pp[2];
-          J[3] = inv_stddev * (-rn.y * lu.z + rn.z * lu.y);      sum += J[3] * pp[3];
-          J[4] = inv_stddev * (rn.x * lu.z - rn.z * lu.x);       sum += J[4] * pp[4];
-          J[5] = inv_stddev * (-rn.x * lu.y + rn.y * lu.x);      sum += J[5] * pp[5];
+          depth_pose_jacobian(inv_stddev, rn, lu, J);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) sum += J[j] * pp[j];
         }
         DepthIntrinsicsTerms t;
         t.valid = false;
@@ -474,11 +462,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
         float J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};
         float Jc1[4] = {0, 0, 0, 0}, Jc2[4] = {0, 0, 0, 0};
         if (P.optimize_geometry) {
-          const float term1 = -(rn.x * ls.z - rn.z * ls.x);
-          const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-          const float term3 = rrcp(ls.z * ls.z);
-          gj1 = -(t.gx1 * term1 + t.gy1 * term2) * term3;
-          gj2 = -(t.gx2 * term1 + t.gy2 * term2) * term3;
+          gj1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);
+          gj2 = descriptor_position_jacobian(t.gx2, t.gy2, 1.f, 1.f, rn, ls);
           sum_1 += gj1 * ps[r][0];
           sum_2 += gj2 * ps[r][0];
           sum_1 += -1.f * ps[r][1];
@@ -493,8 +478,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
         if (kIntr && P.optimize_color_intr) {
           const float gx_1 = t.gx1 / c.cfx, gy_1 = t.gy1 / c.cfy, gx_2 = t.gx2 / c.cfx, gy_2 = t.gy2 / c.cfy;
           const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
-          Jc1[0] = gx_1 * nx; Jc1[1] = gy_1 * ny; Jc1[2] = gx_1; Jc1[3] = gy_1;
-          Jc2[0] = gx_2 * nx; Jc2[1] = gy_2 * ny; Jc2[2] = gx_2; Jc2[3] = gy_2;
+          color_intrinsics_jacobian(gx_1, gy_1, nx, ny, Jc1);
+          color_intrinsics_jacobian(gx_2, gy_2, nx, ny, Jc2);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { sum_1 += Jc1[j] * pci[j]; sum_2 += Jc2[j] * pci[j]; }
         }

@@ -351,6 +351,20 @@ int bslam_debug_pose_residuals(
     const bslam_depth_params* depth_params, const bslam_keyframe_view* keyframe,
     uint32_t surfels_size, const bslam_buffer2d* surfels, float* out);
 
+/* Point-wise probe of the device residual / Jacobian formulas (test aid): evaluates, for `count` points, the functions of
+ * csrc/device_math.hpp that every kernel calls.  HOST in / out, valid on return.  Floats per point (in -> out):
+ *   kind 0 depth / pose          [inv_stddev, n_local(3), lu(3), ls(3)]                        -> [raw residual, J(6)]
+ *   kind 1 depth / position      [inv_stddev]                                                   -> [j]
+ *   kind 2 depth / intrinsics    [inv_stddev, calibrated depth, px, py, nx, ny, n_global(3), frame_T_global row 0 (3), row 1 (3),
+ *                                 n_local(3), cfactor, a, raw_inv_depth]                        -> [corrected_inv_depth, dj(6)]
+ *   kind 3 descriptor / pose     [tl, tr, bl, br, tx, ty, fx, fy, ls(3)]                        -> [bilinear value, gx fx, gy fy, J(6)]
+ *   kind 4 descriptor / position [tl, tr, bl, br, tx, ty, fx, fy, rn(3), ls(3)]                -> [j]
+ *   kind 5 descriptor / colour intrinsics [tl, tr, bl, br, tx, ty, nx, ny]                      -> [j(4)]
+ *   kind 6 = kind 0 in the pose kernel's fused-multiply-add form
+ * (tl .. br = the 2x2 texel footprint in [0, 1], tx, ty = fractional offsets of the sample).  tests/test_gpu_jacobians.py holds
+ * these to the values of the reference's symbolic derivation (applications/badslam/scripts/jacobians_derivation.py). */
+int bslam_debug_jacobians(bslam_context* ctx, void* stream, int kind, int count, const float* in, float* out);
+
 /* ------------------------------------------------------------------------- */
 /* Surfel lifecycle                                          */
 /* ------------------------------------------------------------------------- */

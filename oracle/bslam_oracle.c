@@ -344,6 +344,63 @@ void bso_association_margins(const bslam_camera4f* depth_camera, const bslam_dep
   }
 }
 
+/* Point-wise evaluation of the Jacobian formulas of bso_math.h (the ones every loop of this oracle calls) for
+ * tests/test_jacobian_golden.py.  Layouts (floats per point, in -> out); the HIP entry bslam_debug_jacobians uses the same:
+ *   kind 0 depth / pose          [inv_stddev, n_local(3), lu(3), ls(3)]                                   -> [raw residual, J(6)]
+ *   kind 1 depth / position      [inv_stddev]                                                              -> [j]
+ *   kind 2 depth / intrinsics    [inv_stddev, calibrated depth, px, py, nx, ny, n_global(3), frame_T_global row 0 (3), row 1 (3),
+ *                                 n_local(3), cfactor, a, raw_inv_depth]                                   -> [corrected_inv_depth, dj(6)]
+ *   kind 3 descriptor / pose     [tl, tr, bl, br, tx, ty, fx, fy, ls(3)]                                   -> [bilinear value, gx fx, gy fy, J(6)]
+ *   kind 4 descriptor / position [tl, tr, bl, br, tx, ty, fx, fy, rn(3), ls(3)]                           -> [j]
+ *   kind 5 descriptor / colour intrinsics [tl, tr, bl, br, tx, ty, nx, ny]                                 -> [j(4)]
+ * (tl .. br = the 2x2 texel footprint, tx, ty = fractional offsets of the sample inside it). */
+int bso_jacobian_probe(int kind, int count, const float* in, float* out) {
+  static const int kIn[6] = {10, 1, 21, 11, 14, 8}, kOut[6] = {7, 1, 7, 9, 1, 4};
+  if (kind < 0 || kind > 5) return -1;
+  for (int i = 0; i < count; ++i) {
+    const float* a = in + (size_t)i * kIn[kind];
+    float* o = out + (size_t)i * kOut[kind];
+    switch (kind) {
+      case 0: {
+        const bso_f3 nl = bso_make3(a[1], a[2], a[3]), lu = bso_make3(a[4], a[5], a[6]), ls = bso_make3(a[7], a[8], a[9]);
+        o[0] = bso_depth_residual(a[0], nl, lu, ls);
+        bso_jac_depth_pose(a[0], nl, lu, o + 1);
+        break;
+      }
+      case 1: o[0] = bso_jac_depth_position(a[0]); break;
+      case 2: {
+        const float m[12] = {a[9], a[10], a[11], 0, a[12], a[13], a[14], 0, 0, 0, 0, 0};
+        o[0] = bso_jac_depth_intrinsics(a[0], a[1], (int)a[2], (int)a[3], a[4], a[5], bso_make3(a[6], a[7], a[8]), m, bso_make3(a[15], a[16], a[17]),
+                                        a[18], a[19], a[20], o + 1);
+        break;
+      }
+      case 3: {
+        float dx, dy;
+        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        const float w00 = (1.0f - a[4]) * (1.0f - a[5]), w10 = a[4] * (1.0f - a[5]), w01 = (1.0f - a[4]) * a[5], w11 = a[4] * a[5];
+        o[0] = ((w00 * a[0] + w10 * a[1]) + w01 * a[2]) + w11 * a[3];       /* the filter of bso_tex_w */
+        o[1] = dx * a[6];
+        o[2] = dy * a[7];
+        bso_jac_desc_pose(o[1], o[2], bso_make3(a[8], a[9], a[10]), o + 3);
+        break;
+      }
+      case 4: {
+        float dx, dy;
+        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        o[0] = bso_jac_desc_position(dx, dy, a[6], a[7], bso_make3(a[8], a[9], a[10]), bso_make3(a[11], a[12], a[13]));
+        break;
+      }
+      case 5: {
+        float dx, dy;
+        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        bso_jac_desc_color_intrinsics(dx, dy, a[6], a[7], o);
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
 /* ========================================================================== */
 /* pose optimisation                                                           */
 /* ========================================================================== */
@@ -364,20 +421,6 @@ static void accumulate_h_and_b(float raw_residual, float weight, const float* J,
     b[i] += v;
     if (b64) b64[i] += (double)v;
   }
-}
-
-/* BS/kernel_opt_pose.cu:100-144 */
-static void descriptor_pose_jacobian(float gx, float gy, bso_f3 ls, float* J) {
-  float inv_ls_z = 1.f / ls.z;
-  float ls_z_sq = ls.z * ls.z;
-  float inv_ls_z_sq = inv_ls_z * inv_ls_z;
-  J[0] = -gx * inv_ls_z;
-  J[1] = -gy * inv_ls_z;
-  J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
-  float ls_x_y = ls.x * ls.y;
-  J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
-  J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
-  J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
 }
 
 void bso_accumulate_pose_estimation_coeffs(
@@ -413,13 +456,8 @@ void bso_accumulate_pose_estimation_coeffs(
       float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&unproj, r.px), bso_unproj_ny(&unproj, r.py), r.calibrated_depth, n_local, dp->baseline_fx);
       /* ComputeRawDepthResidualAndJacobian BS/kernel_opt_pose.cu:45-94 */
       bso_f3 local_unproj = bso_unproject(&unproj, r.px, r.py, r.calibrated_depth);
-      raw_residual = inv_stddev * bso_dot(n_local, bso_sub(local_unproj, r.local_position));
-      J[0] = inv_stddev * n_local.x;
-      J[1] = inv_stddev * n_local.y;
-      J[2] = inv_stddev * n_local.z;
-      J[3] = inv_stddev * (-n_local.y * local_unproj.z + n_local.z * local_unproj.y);
-      J[4] = inv_stddev * (n_local.x * local_unproj.z - n_local.z * local_unproj.x);
-      J[5] = inv_stddev * (-n_local.x * local_unproj.y + n_local.y * local_unproj.x);
+      raw_residual = bso_depth_residual(inv_stddev, n_local, local_unproj, r.local_position);
+      bso_jac_depth_pose(inv_stddev, n_local, local_unproj, J);
       float w = bso_depth_weight(raw_residual);
       accumulate_h_and_b(raw_residual, w, J, H, b, H64, b64);
       count += 1;
@@ -441,8 +479,8 @@ void bso_accumulate_pose_estimation_coeffs(
         gx1 *= color_center_fx; gx2 *= color_center_fx;
         gy1 *= color_center_fy; gy2 *= color_center_fy;
         float J1[6], J2[6];
-        descriptor_pose_jacobian(gx1, gy1, r.local_position, J1);
-        descriptor_pose_jacobian(gx2, gy2, r.local_position, J2);
+        bso_jac_desc_pose(gx1, gy1, r.local_position, J1);
+        bso_jac_desc_pose(gx2, gy2, r.local_position, J2);
         float w1 = bso_desc_weight(r1), w2 = bso_desc_weight(r2);
         accumulate_h_and_b(r1, w1, J1, H, b, H64, b64);
         accumulate_h_and_b(r2, w2, J2, H, b, H64, b64);
@@ -656,9 +694,9 @@ void bso_optimize_geometry_iteration(
         if (!bso_surfel_projects_to_associated_pixel(i, surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r)) continue;
         bso_f3 rn = bso_rotate34(&kf->frame_T_global, r.surfel_normal);
         float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&unproj, r.px), bso_unproj_ny(&unproj, r.py), r.calibrated_depth, rn, dp->baseline_fx);
-        const float depth_jacobian = -inv_stddev;
+        const float depth_jacobian = bso_jac_depth_position(inv_stddev);
         bso_f3 local_unproj = bso_unproject(&unproj, r.px, r.py, r.calibrated_depth);
-        float raw = inv_stddev * bso_dot(rn, bso_sub(local_unproj, r.local_position));
+        float raw = bso_depth_residual(inv_stddev, rn, local_unproj, r.local_position);
         const float w = bso_depth_weight(raw);
         float weighted_jacobian = w * depth_jacobian;
         ACC(surfels, 0, i) += weighted_jacobian * depth_jacobian;
@@ -692,9 +730,9 @@ void bso_optimize_geometry_iteration(
         bso_f3 rn = bso_rotate34(&kf->frame_T_global, r.surfel_normal);
         if (use_depth_residuals) {
           float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&unproj, r.px), bso_unproj_ny(&unproj, r.py), r.calibrated_depth, rn, dp->baseline_fx);
-          const float depth_jacobian = -inv_stddev;
+          const float depth_jacobian = bso_jac_depth_position(inv_stddev);
           bso_f3 local_unproj = bso_unproject(&unproj, r.px, r.py, r.calibrated_depth);
-          float raw = inv_stddev * bso_dot(rn, bso_sub(local_unproj, r.local_position));
+          float raw = bso_depth_residual(inv_stddev, rn, local_unproj, r.local_position);
           const float w = bso_depth_weight(raw);
           ACC(surfels, 0, i) += w * depth_jacobian * depth_jacobian;
           ACC(surfels, 6, i) += w * raw * depth_jacobian;
@@ -710,11 +748,8 @@ void bso_optimize_geometry_iteration(
           bso_raw_descriptor_residual(&kf->color, tex_mode, color_pxy, t1, t2, d1, d2, &r1, &r2);
           float gx1, gy1, gx2, gy2;
           bso_descriptor_jacobian_wrt_projected_position(&kf->color, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
-          const float term1 = -color_camera->fx * (rn.x * r.local_position.z - rn.z * r.local_position.x);
-          const float term2 = -color_camera->fy * (rn.y * r.local_position.z - rn.z * r.local_position.y);
-          const float term3 = 1.f / (r.local_position.z * r.local_position.z);
-          float jp1 = -(gx1 * term1 + gy1 * term2) * term3;
-          float jp2 = -(gx2 * term1 + gy2 * term2) * term3;
+          float jp1 = bso_jac_desc_position(gx1, gy1, color_camera->fx, color_camera->fy, rn, r.local_position);
+          float jp2 = bso_jac_desc_position(gx2, gy2, color_camera->fx, color_camera->fy, rn, r.local_position);
           const float jd = -1.f;
           const float w1 = bso_desc_weight(r1);
           const float wr1 = w1 * r1;

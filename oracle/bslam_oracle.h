@@ -243,6 +243,8 @@ void bso_track_frame_pairwise(
     const bslam_buffer2d* base_depth_u16, const bslam_buffer2d* base_normals, const bslam_buffer2d* base_color_uchar4, int tex_mode,
     int test_different_initial_estimates, const bslam_se3f* init1, const bslam_se3f* init2, bslam_se3f* out_base_T_frame, int* iterations_per_scale);
 
+/* point-wise Jacobian formulas (layouts in bslam_oracle.c) */
+int bso_jacobian_probe(int kind, int count, const float* in, float* out);
 /* 1: the global blocks of bso_optimize_intrinsics are float64 sums of the fp32 terms (default 0: serial fp32) */
 void bso_set_intrinsics_sum64(int enable);
 /* evaluation shape of bso_math.h: 0 = twin of the HIP kernels (default), 1 = literal transcription of the reference */

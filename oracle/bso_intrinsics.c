@@ -66,22 +66,15 @@ void bso_optimize_intrinsics(
           const int sparse_px = r.px / dp->sparse_surfel_cell_size, sparse_py = r.py / dp->sparse_surfel_cell_size;
           const float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
           const float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-          const float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
-          const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+          const bso_f3 ln = bso_rotate34(&kf->frame_T_global, r.surfel_normal);
+          const float inv_stddev = bso_depth_inv_stddev(nx, ny, r.calibrated_depth, ln, dp->baseline_fx);
+          float dj_all[6];
+          const float corrected_inv_depth = bso_jac_depth_intrinsics(inv_stddev, r.calibrated_depth, r.px, r.py, nx, ny, r.surfel_normal,
+                                                                     kf->frame_T_global.m, ln, cfactor, dp->a, raw_inv_depth, dj_all);
           if (fabsf(corrected_inv_depth) > 1e-4f) {
-            const bso_f3 ln = bso_rotate34(&kf->frame_T_global, r.surfel_normal);
-            const float dot = bso_dot(bso_make3(nx, ny, 1), ln);
-            const float inv_stddev = bso_depth_inv_stddev(nx, ny, r.calibrated_depth, ln, dp->baseline_fx);
-            const float jac_base = inv_stddev * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
-            const float* m = kf->frame_T_global.m;
-            dj[2] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[0], m[1], m[2]));
-            dj[3] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[4], m[5], m[6]));
-            dj[0] = r.px * dj[2];
-            dj[1] = r.py * dj[3];
-            dj[4] = cfactor * raw_inv_depth * jac_base;
-            dj[5] = -jac_base;
+            for (int q = 0; q < 6; ++q) dj[q] = dj_all[q];
             const bso_f3 lu = bso_make3(r.calibrated_depth * nx, r.calibrated_depth * ny, r.calibrated_depth);
-            raw_depth = inv_stddev * bso_dot(ln, bso_sub(lu, r.local_position));
+            raw_depth = bso_depth_residual(inv_stddev, ln, lu, r.local_position);
             cell = sparse_px + sparse_py * cw;
           }
         }
@@ -93,8 +86,8 @@ void bso_optimize_intrinsics(
                                     &kf->frame_T_global, color_camera->fx, color_camera->fy, color_camera->cx, color_camera->cy, &t1, &t2);
             float gx1, gy1, gx2, gy2;
             bso_descriptor_jacobian_wrt_projected_position(&kf->color, color_pxy, t1, t2, &gx1, &gy1, &gx2, &gy2);
-            j1[0] = gx1 * nx; j1[1] = gy1 * ny; j1[2] = gx1; j1[3] = gy1;
-            j2[0] = gx2 * nx; j2[1] = gy2 * ny; j2[2] = gx2; j2[3] = gy2;
+            bso_jac_desc_color_intrinsics(gx1, gy1, nx, ny, j1);
+            bso_jac_desc_color_intrinsics(gx2, gy2, nx, ny, j2);
             bso_raw_descriptor_residual(&kf->color, tex_mode, color_pxy, t1, t2, BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR1, i),
                                         BSO_AT(float, surfels, BSLAM_SURFEL_DESCRIPTOR2, i), &r1, &r2);
           }

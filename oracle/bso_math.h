@@ -300,6 +300,84 @@ static inline float bso_weighted_depth_residual(float r) { return BSO_DEPTH_RESI
 static inline float bso_desc_weight(float r) { return 1.f * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_weight(r, BSO_DESC_HUBER); }            /* :177-179 */
 static inline float bso_weighted_desc_residual(float r) { return 1.f * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_residual(r, BSO_DESC_HUBER); }  /* :183-185 */
 
+/* ---- Jacobians ---------------------------------------------------------------------------------------
+ * One definition per formula, used by every loop of the oracle (pose, geometry, PCG, intrinsics, odometry) and pinned
+ * against the reference's own symbolic derivation (applications/badslam/scripts/jacobians_derivation.py, evaluated into
+ * tests/golden/jacobian_golden.npz; tests/test_jacobian_golden.py).  The reference repeats these expressions in each
+ * kernel; the citations name the first occurrence. */
+
+/* Depth residual and its Jacobian wrt. the pose delta (BS/kernel_opt_pose.cu:45-94, BS/cost_function.cuh:56-68):
+ * n_local = surfel normal in the frame, lu = unprojected pixel, ls = surfel position in the frame. */
+static inline float bso_depth_residual(float inv_stddev, bso_f3 n_local, bso_f3 lu, bso_f3 ls) {
+  return inv_stddev * bso_dot(n_local, bso_sub(lu, ls));
+}
+static inline void bso_jac_depth_pose(float inv_stddev, bso_f3 n_local, bso_f3 lu, float* J) {
+  J[0] = inv_stddev * n_local.x;
+  J[1] = inv_stddev * n_local.y;
+  J[2] = inv_stddev * n_local.z;
+  J[3] = inv_stddev * (-n_local.y * lu.z + n_local.z * lu.y);
+  J[4] = inv_stddev * (n_local.x * lu.z - n_local.z * lu.x);
+  J[5] = inv_stddev * (-n_local.x * lu.y + n_local.y * lu.x);
+}
+/* Depth residual wrt. a surfel move of t along its (unit) normal (BS/kernel_opt_geometry.cu:440, BS/kernel_pcg.cu:217). */
+static inline float bso_jac_depth_position(float inv_stddev) { return -inv_stddev; }
+
+/* Descriptor residual wrt. the pose delta (BS/kernel_opt_pose.cu:100-144); gx, gy = image gradient of the residual in
+ * intensity per pixel TIMES the colour camera's fx, fy; ls = surfel position in the frame. */
+static inline void bso_jac_desc_pose(float gx, float gy, bso_f3 ls, float* J) {
+  float inv_ls_z = 1.f / ls.z;
+  float ls_z_sq = ls.z * ls.z;
+  float inv_ls_z_sq = inv_ls_z * inv_ls_z;
+  J[0] = -gx * inv_ls_z;
+  J[1] = -gy * inv_ls_z;
+  J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
+  float ls_x_y = ls.x * ls.y;
+  J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
+  J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
+  J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+}
+/* Descriptor residual wrt. a surfel move along its normal (BS/kernel_opt_geometry.cu:175-189, BS/kernel_pcg.cu:364-372):
+ * rn = normal in the frame, ls = position in the frame; the gradient (gx, gy) is multiplied by (fx, fy) here (the PCG
+ * kernels pass gradients that already carry the focal lengths and fx = fy = 1). */
+static inline float bso_jac_desc_position(float gx, float gy, float fx, float fy, bso_f3 rn, bso_f3 ls) {
+  const float term1 = -fx * (rn.x * ls.z - rn.z * ls.x);
+  const float term2 = -fy * (rn.y * ls.z - rn.z * ls.y);
+  const float term3 = 1.f / (ls.z * ls.z);
+  return -(gx * term1 + gy * term2) * term3;
+}
+/* Depth residual wrt. (fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor of the pixel's cell), dj[0..5]
+ * (BS/kernel_opt_intrinsics.cu:82-118 = BS/kernel_pcg.cu:258-322).  m = frame_T_global (3x4 row-major), ln = normal in
+ * the frame.  Returns corrected_inv_depth, on which the callers base their validity tests (:90, BS/kernel_pcg.cu:272). */
+static inline float bso_jac_depth_intrinsics(float inv_stddev, float calibrated_depth, int px, int py, float nx, float ny, bso_f3 n_global,
+                                             const float* m, bso_f3 ln, float cfactor, float a, float raw_inv_depth, float* dj) {
+  const float exp_inv_depth = BSO_LITERAL ? expf(-a * raw_inv_depth) : bso_expf(-a * raw_inv_depth);
+  const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+  const float dot = bso_dot(bso_make3(nx, ny, 1), ln);
+  const float jac_base = inv_stddev * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
+  dj[2] = inv_stddev * calibrated_depth * bso_dot(n_global, bso_make3(m[0], m[1], m[2]));
+  dj[3] = inv_stddev * calibrated_depth * bso_dot(n_global, bso_make3(m[4], m[5], m[6]));
+  dj[0] = px * dj[2];
+  dj[1] = py * dj[3];
+  dj[4] = cfactor * raw_inv_depth * jac_base;
+  dj[5] = -jac_base;
+  return corrected_inv_depth;
+}
+/* Descriptor residual wrt. the colour camera's (fx, fy, cx, cy) (BS/kernel_opt_intrinsics.cu:141-149, BS/kernel_pcg.cu:462-509):
+ * gx, gy = image gradient of the residual (no focal length), nx, ny = normalised image coordinates of the pixel. */
+static inline void bso_jac_desc_color_intrinsics(float gx, float gy, float nx, float ny, float* j) {
+  j[0] = gx * nx;
+  j[1] = gy * ny;
+  j[2] = gx;
+  j[3] = gy;
+}
+/* Image gradient of a bilinear sample from its 2x2 texel footprint and the sample's fractional offsets (tx, ty)
+ * (one block of BS/cost_function.cuh:200-239). */
+static inline void bso_bilinear_gradient(float top_left, float top_right, float bottom_left, float bottom_right, float tx, float ty,
+                                         float* dx, float* dy) {
+  *dx = (bottom_right - bottom_left) * ty + (top_right - top_left) * (1 - ty);
+  *dy = (bottom_right - top_right) * tx + (bottom_left - top_left) * (1 - tx);
+}
+
 /* ---- software model of the colour texture (BS/keyframe.cc:67-73) --------------
  * pitch2D uchar4, clamp addressing, cudaFilterModeLinear, cudaReadModeNormalizedFloat,
  * unnormalised coordinates; only the .w channel (luma) is ever read on this path.
@@ -381,8 +459,7 @@ static inline void bso_point_gradient(const bslam_buffer2d* color, bso_f2 p, flo
   float top_right = bso_texel_w(color, ix + 1, iy);
   float bottom_left = bso_texel_w(color, ix, iy + 1);
   float bottom_right = bso_texel_w(color, ix + 1, iy + 1);
-  *dx = (bottom_right - bottom_left) * ty + (top_right - top_left) * (1 - ty);
-  *dy = (bottom_right - top_right) * tx + (bottom_left - top_left) * (1 - tx);
+  bso_bilinear_gradient(top_left, top_right, bottom_left, bottom_right, tx, ty, dx, dy);
 }
 
 /* BS/cost_function.cuh:191-254 (the three unused fetches :241-243 are dropped, quirk Q3) */

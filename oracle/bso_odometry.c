@@ -161,14 +161,8 @@ static void evaluate_pixel(int x, int y, int use_depth, int use_desc, int need_j
   if (use_depth) {
     const float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&u, px), bso_unproj_ny(&u, py), pixel_depth, n_local, baseline_fx);
     const bso_f3 lu = bso_unproject(&u, px, py, pixel_depth);
-    t->raw_depth_residual = inv_stddev * bso_dot(n_local, bso_sub(lu, local));
-    float* J = t->depth_jacobian;
-    J[0] = inv_stddev * n_local.x;
-    J[1] = inv_stddev * n_local.y;
-    J[2] = inv_stddev * n_local.z;
-    J[3] = inv_stddev * (-n_local.y * lu.z + n_local.z * lu.y);
-    J[4] = inv_stddev * (n_local.x * lu.z - n_local.z * lu.x);
-    J[5] = inv_stddev * (-n_local.x * lu.y + n_local.y * lu.x);
+    t->raw_depth_residual = bso_depth_residual(inv_stddev, n_local, lu, local);
+    bso_jac_depth_pose(inv_stddev, n_local, lu, t->depth_jacobian);
   }
   if (use_desc) {
     if (x < surfel_depth->width - 1 && y < surfel_depth->height - 1) {
@@ -201,14 +195,8 @@ static void evaluate_pixel(int x, int y, int use_depth, int use_desc, int need_j
           float gx1 = 180.f * (t1dx - cdx), gy1 = 180.f * (t1dy - cdy), gx2 = 180.f * (t2dx - cdx), gy2 = 180.f * (t2dy - cdy);
           gx1 *= color_camera->fx; gx2 *= color_camera->fx;
           gy1 *= color_camera->fy; gy2 *= color_camera->fy;
-          const bso_f3 ls = local;
-          const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
-          float* J = t->J1;
-          J[0] = -gx1 * inv_z; J[1] = -gy1 * inv_z; J[2] = (ls.x * gx1 + ls.y * gy1) * inv_z_sq;
-          J[3] = ((ls.y * ls.y + z_sq) * gy1 + xy * gx1) * inv_z_sq; J[4] = -((ls.x * ls.x + z_sq) * gx1 + xy * gy1) * inv_z_sq; J[5] = -(ls.x * gy1 - ls.y * gx1) * inv_z;
-          J = t->J2;
-          J[0] = -gx2 * inv_z; J[1] = -gy2 * inv_z; J[2] = (ls.x * gx2 + ls.y * gy2) * inv_z_sq;
-          J[3] = ((ls.y * ls.y + z_sq) * gy2 + xy * gx2) * inv_z_sq; J[4] = -((ls.x * ls.x + z_sq) * gx2 + xy * gy2) * inv_z_sq; J[5] = -(ls.x * gy2 - ls.y * gx2) * inv_z;
+          bso_jac_desc_pose(gx1, gy1, local, t->J1);
+          bso_jac_desc_pose(gx2, gy2, local, t->J2);
         }
       } else {
         visible = 0;

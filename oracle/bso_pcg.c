@@ -61,45 +61,37 @@ static void pcg_init_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* c
     if (l->use_depth_residuals) {
       float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), r.calibrated_depth, rn, dp->baseline_fx);
       bso_f3 lu = bso_unproject(&c->unproj, r.px, r.py, r.calibrated_depth);
-      float raw = inv_stddev * bso_dot(rn, bso_sub(lu, r.local_position));
+      float raw = bso_depth_residual(inv_stddev, rn, lu, r.local_position);
       const float weight = bso_depth_weight(raw);
       int vis = visible;
       if (l->optimize_geometry) {                                           /* :217-221 */
-        const float jp = -inv_stddev;
+        const float jp = bso_jac_depth_position(inv_stddev);
         v->r[l->surfel_unknown_start_index + per_surfel * i] -= jp * weight * raw;
         v->M[l->surfel_unknown_start_index + per_surfel * i] += jp * weight * jp;
       }
       if (optimize_poses) {                                                 /* :224-255 */
-        sum_r_and_m(v, kf_idx + 0, inv_stddev * rn.x, weight, raw);
-        sum_r_and_m(v, kf_idx + 1, inv_stddev * rn.y, weight, raw);
-        sum_r_and_m(v, kf_idx + 2, inv_stddev * rn.z, weight, raw);
-        sum_r_and_m(v, kf_idx + 3, inv_stddev * (-rn.y * lu.z + rn.z * lu.y), weight, raw);
-        sum_r_and_m(v, kf_idx + 4, inv_stddev * (rn.x * lu.z - rn.z * lu.x), weight, raw);
-        sum_r_and_m(v, kf_idx + 5, inv_stddev * (-rn.x * lu.y + rn.y * lu.x), weight, raw);
+        float J[6];
+        bso_jac_depth_pose(inv_stddev, rn, lu, J);
+        for (int q = 0; q < 6; ++q) sum_r_and_m(v, kf_idx + q, J[q], weight, raw);
       }
       if (l->optimize_depth_intrinsics) {                                   /* :258-322 */
         int sparse_px = r.px / dp->sparse_surfel_cell_size;
         int sparse_py = r.py / dp->sparse_surfel_cell_size;
         float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
         float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-        float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
-        float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+        float dj[6];
+        const float corrected_inv_depth = bso_jac_depth_intrinsics(inv_stddev, r.calibrated_depth, r.px, r.py, bso_unproj_nx(&c->unproj, r.px),
+                                                                   bso_unproj_ny(&c->unproj, r.py), r.surfel_normal, kf->frame_T_global.m, rn,
+                                                                   cfactor, dp->a, raw_inv_depth, dj);
         if (fabsf(corrected_inv_depth) < 1e-4f) vis = 0;                    /* NOTE: stays false for the descriptor part too (:272) */
-        float nx = bso_unproj_nx(&c->unproj, r.px);
-        float ny = bso_unproj_ny(&c->unproj, r.py);
-        float dot = bso_dot(bso_make3(nx, ny, 1), rn);
-        float jac_base = inv_stddev * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
-        const float* m = kf->frame_T_global.m;
-        float d_cx_inv = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[0], m[1], m[2]));
-        float d_cy_inv = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[4], m[5], m[6]));
         if (vis) {
           const uint32_t d0 = l->depth_intrinsics_unknown_start_index;
-          sum_r_and_m(v, d0 + 2, d_cx_inv, weight, raw);
-          sum_r_and_m(v, d0 + 3, d_cy_inv, weight, raw);
-          sum_r_and_m(v, d0 + 0, r.px * d_cx_inv, weight, raw);
-          sum_r_and_m(v, d0 + 1, r.py * d_cy_inv, weight, raw);
-          sum_r_and_m(v, d0 + 4, cfactor * raw_inv_depth * jac_base, weight, raw);
-          sum_r_and_m(v, d0 + 5 + sparse_px + sparse_py * dp->cfactor_buffer.width, -jac_base, weight, raw);
+          sum_r_and_m(v, d0 + 2, dj[2], weight, raw);
+          sum_r_and_m(v, d0 + 3, dj[3], weight, raw);
+          sum_r_and_m(v, d0 + 0, dj[0], weight, raw);
+          sum_r_and_m(v, d0 + 1, dj[1], weight, raw);
+          sum_r_and_m(v, d0 + 4, dj[4], weight, raw);
+          sum_r_and_m(v, d0 + 5 + sparse_px + sparse_py * dp->cfactor_buffer.width, dj[5], weight, raw);
         }
         visible = vis;
       }
@@ -121,11 +113,8 @@ static void pcg_init_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* c
       const float w1 = bso_desc_weight(r1), w2 = bso_desc_weight(r2);
       const bso_f3 ls = r.local_position;
       if (l->optimize_geometry) {                                           /* :364-399 */
-        const float term1 = -(rn.x * ls.z - rn.z * ls.x);
-        const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-        const float term3 = 1.f / (ls.z * ls.z);
-        float jp1 = -(gx1 * term1 + gy1 * term2) * term3;
-        float jp2 = -(gx2 * term1 + gy2 * term2) * term3;
+        float jp1 = bso_jac_desc_position(gx1, gy1, 1.f, 1.f, rn, ls);   /* gx, gy already carry fx, fy */
+        float jp2 = bso_jac_desc_position(gx2, gy2, 1.f, 1.f, rn, ls);
         const uint32_t s0 = l->surfel_unknown_start_index + 3 * i;
         v->r[s0 + 0] -= jp1 * w1 * r1 + jp2 * w2 * r2;
         v->M[s0 + 0] += jp1 * w1 * jp1 + jp2 * w2 * jp2;
@@ -136,27 +125,19 @@ static void pcg_init_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* c
         v->M[s0 + 2] += j21 * w1 * j21 + j22 * w2 * j22;
       }
       if (optimize_poses) {                                                 /* :402-459 */
-        float inv_ls_z = 1.f / ls.z;
-        float ls_z_sq = ls.z * ls.z;
-        float inv_ls_z_sq = inv_ls_z * inv_ls_z;
-        sum_r_and_m2(v, kf_idx + 0, -gx1 * inv_ls_z, w1, r1, -gx2 * inv_ls_z, w2, r2);
-        sum_r_and_m2(v, kf_idx + 1, -gy1 * inv_ls_z, w1, r1, -gy2 * inv_ls_z, w2, r2);
-        sum_r_and_m2(v, kf_idx + 2, (ls.x * gx1 + ls.y * gy1) * inv_ls_z_sq, w1, r1, (ls.x * gx2 + ls.y * gy2) * inv_ls_z_sq, w2, r2);
-        float ls_x_y = ls.x * ls.y;
-        const float term1 = ls.y * ls.y + ls_z_sq;
-        sum_r_and_m2(v, kf_idx + 3, (term1 * gy1 + ls_x_y * gx1) * inv_ls_z_sq, w1, r1, (term1 * gy2 + ls_x_y * gx2) * inv_ls_z_sq, w2, r2);
-        const float term2 = ls.x * ls.x + ls_z_sq;
-        sum_r_and_m2(v, kf_idx + 4, -(term2 * gx1 + ls_x_y * gy1) * inv_ls_z_sq, w1, r1, -(term2 * gx2 + ls_x_y * gy2) * inv_ls_z_sq, w2, r2);
-        sum_r_and_m2(v, kf_idx + 5, -(ls.x * gy1 - ls.y * gx1) * inv_ls_z, w1, r1, -(ls.x * gy2 - ls.y * gx2) * inv_ls_z, w2, r2);
+        float J1[6], J2[6];
+        bso_jac_desc_pose(gx1, gy1, ls, J1);
+        bso_jac_desc_pose(gx2, gy2, ls, J2);
+        for (int q = 0; q < 6; ++q) sum_r_and_m2(v, kf_idx + q, J1[q], w1, r1, J2[q], w2, r2);
       }
       if (l->optimize_color_intrinsics) {                                   /* :462-509 */
         const float g_x_1 = gx1 / color_camera->fx, g_y_1 = gy1 / color_camera->fy;
         const float g_x_2 = gx2 / color_camera->fx, g_y_2 = gy2 / color_camera->fy;
         const uint32_t c0 = l->color_intrinsics_unknown_start_index;
-        sum_r_and_m2(v, c0 + 0, g_x_1 * bso_unproj_nx(&c->unproj, r.px), w1, r1, g_x_2 * bso_unproj_nx(&c->unproj, r.px), w2, r2);
-        sum_r_and_m2(v, c0 + 1, g_y_1 * bso_unproj_ny(&c->unproj, r.py), w1, r1, g_y_2 * bso_unproj_ny(&c->unproj, r.py), w2, r2);
-        sum_r_and_m2(v, c0 + 2, g_x_1, w1, r1, g_x_2, w2, r2);
-        sum_r_and_m2(v, c0 + 3, g_y_1, w1, r1, g_y_2, w2, r2);
+        float c1[4], c2[4];
+        bso_jac_desc_color_intrinsics(g_x_1, g_y_1, bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), c1);
+        bso_jac_desc_color_intrinsics(g_x_2, g_y_2, bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), c2);
+        for (int q = 0; q < 4; ++q) sum_r_and_m2(v, c0 + q, c1[q], w1, r1, c2[q], w2, r2);
       }
     }
   }
@@ -206,7 +187,7 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
     if (l->use_depth_residuals) {
       float inv_stddev = bso_depth_inv_stddev(bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), r.calibrated_depth, rn, dp->baseline_fx);
       bso_f3 lu = bso_unproject(&c->unproj, r.px, r.py, r.calibrated_depth);
-      float raw = inv_stddev * bso_dot(rn, bso_sub(lu, r.local_position));
+      float raw = bso_depth_residual(inv_stddev, rn, lu, r.local_position);
       const float weight = bso_depth_weight(raw);
       float sum = 0;
       float geometry_jacobian = 0;
@@ -214,16 +195,12 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
       float dgi[5] = {0, 0, 0, 0, 0};
       float cfactor_entry_jacobian = 0;
       if (l->optimize_geometry) {
-        geometry_jacobian = -inv_stddev;
+        geometry_jacobian = bso_jac_depth_position(inv_stddev);
         sum += geometry_jacobian * v->p[l->surfel_unknown_start_index + per_surfel * i + 0];
       }
       if (optimize_poses) {
-        pose_jacobian[0] = inv_stddev * rn.x;                          sum += pose_jacobian[0] * v->p[kf_idx + 0];
-        pose_jacobian[1] = inv_stddev * rn.y;                          sum += pose_jacobian[1] * v->p[kf_idx + 1];
-        pose_jacobian[2] = inv_stddev * rn.z;                          sum += pose_jacobian[2] * v->p[kf_idx + 2];
-        pose_jacobian[3] = inv_stddev * (-rn.y * lu.z + rn.z * lu.y);  sum += pose_jacobian[3] * v->p[kf_idx + 3];
-        pose_jacobian[4] = inv_stddev * (rn.x * lu.z - rn.z * lu.x);   sum += pose_jacobian[4] * v->p[kf_idx + 4];
-        pose_jacobian[5] = inv_stddev * (-rn.x * lu.y + rn.y * lu.x);  sum += pose_jacobian[5] * v->p[kf_idx + 5];
+        bso_jac_depth_pose(inv_stddev, rn, lu, pose_jacobian);
+        for (int q = 0; q < 6; ++q) sum += pose_jacobian[q] * v->p[kf_idx + q];
       }
       int djv = 0;
       uint32_t cfactor_entry_index = 0;
@@ -232,28 +209,21 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
         int sparse_py = r.py / dp->sparse_surfel_cell_size;
         float cfactor = BSO_AT(float, &dp->cfactor_buffer, sparse_py, sparse_px);
         float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * BSO_AT(uint16_t, &kf->depth, r.py, r.px));
-        float exp_inv_depth = bso_expf(-dp->a * raw_inv_depth);
-        float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
+        float dj[6];
+        const float corrected_inv_depth = bso_jac_depth_intrinsics(inv_stddev, r.calibrated_depth, r.px, r.py, bso_unproj_nx(&c->unproj, r.px),
+                                                                   bso_unproj_ny(&c->unproj, r.py), r.surfel_normal, kf->frame_T_global.m, rn,
+                                                                   cfactor, dp->a, raw_inv_depth, dj);
         djv = !(fabsf(corrected_inv_depth) < 1e-4f);
         if (djv) {
           const uint32_t d0 = l->depth_intrinsics_unknown_start_index;
-          float nx = bso_unproj_nx(&c->unproj, r.px);
-          float ny = bso_unproj_ny(&c->unproj, r.py);
-          float dot = bso_dot(bso_make3(nx, ny, 1), rn);
-          float jac_base = inv_stddev * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
-          const float* m = kf->frame_T_global.m;
-          dgi[2] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[0], m[1], m[2]));
+          for (int q = 0; q < 5; ++q) dgi[q] = dj[q];
           sum += dgi[2] * v->p[d0 + 2];
-          dgi[3] = inv_stddev * r.calibrated_depth * bso_dot(r.surfel_normal, bso_make3(m[4], m[5], m[6]));
           sum += dgi[3] * v->p[d0 + 3];
-          dgi[0] = r.px * dgi[2];
           sum += dgi[0] * v->p[d0 + 0];
-          dgi[1] = r.py * dgi[3];
           sum += dgi[1] * v->p[d0 + 1];
-          dgi[4] = cfactor * raw_inv_depth * jac_base;
           sum += dgi[4] * v->p[d0 + 4];
           cfactor_entry_index = d0 + 5 + sparse_px + sparse_py * dp->cfactor_buffer.width;
-          cfactor_entry_jacobian = -jac_base;
+          cfactor_entry_jacobian = dj[5];
           sum += cfactor_entry_jacobian * v->p[cfactor_entry_index];
         }
       }
@@ -289,11 +259,8 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
       float cj1[4] = {0, 0, 0, 0}, cj2[4] = {0, 0, 0, 0};
       const uint32_t s0 = l->surfel_unknown_start_index + 3 * i;
       if (l->optimize_geometry) {
-        const float term1 = -(rn.x * ls.z - rn.z * ls.x);
-        const float term2 = -(rn.y * ls.z - rn.z * ls.y);
-        const float term3 = 1.f / (ls.z * ls.z);
-        gj1 = -(gx1 * term1 + gy1 * term2) * term3;
-        gj2 = -(gx2 * term1 + gy2 * term2) * term3;
+        gj1 = bso_jac_desc_position(gx1, gy1, 1.f, 1.f, rn, ls);
+        gj2 = bso_jac_desc_position(gx2, gy2, 1.f, 1.f, rn, ls);
         float p = v->p[s0 + 0];
         sum_1 += gj1 * p;
         sum_2 += gj2 * p;
@@ -303,47 +270,25 @@ static void pcg_step1_keyframe(const bslam_pcg_layout* l, const bslam_camera4f* 
         sum_2 += -1.f * p;
       }
       if (optimize_poses) {
-        float inv_ls_z = 1.f / ls.z;
-        float ls_z_sq = ls.z * ls.z;
-        float inv_ls_z_sq = inv_ls_z * inv_ls_z;
-        float p = v->p[kf_idx + 0];
-        pj1[0] = -gx1 * inv_ls_z; sum_1 += pj1[0] * p;
-        pj2[0] = -gx2 * inv_ls_z; sum_2 += pj2[0] * p;
-        p = v->p[kf_idx + 1];
-        pj1[1] = -gy1 * inv_ls_z; sum_1 += pj1[1] * p;
-        pj2[1] = -gy2 * inv_ls_z; sum_2 += pj2[1] * p;
-        p = v->p[kf_idx + 2];
-        pj1[2] = (ls.x * gx1 + ls.y * gy1) * inv_ls_z_sq; sum_1 += pj1[2] * p;
-        pj2[2] = (ls.x * gx2 + ls.y * gy2) * inv_ls_z_sq; sum_2 += pj2[2] * p;
-        float ls_x_y = ls.x * ls.y;
-        p = v->p[kf_idx + 3];
-        const float term1 = ls.y * ls.y + ls_z_sq;
-        pj1[3] = (term1 * gy1 + ls_x_y * gx1) * inv_ls_z_sq; sum_1 += pj1[3] * p;
-        pj2[3] = (term1 * gy2 + ls_x_y * gx2) * inv_ls_z_sq; sum_2 += pj2[3] * p;
-        p = v->p[kf_idx + 4];
-        const float term2 = ls.x * ls.x + ls_z_sq;
-        pj1[4] = -(term2 * gx1 + ls_x_y * gy1) * inv_ls_z_sq; sum_1 += pj1[4] * p;
-        pj2[4] = -(term2 * gx2 + ls_x_y * gy2) * inv_ls_z_sq; sum_2 += pj2[4] * p;
-        p = v->p[kf_idx + 5];
-        pj1[5] = -(ls.x * gy1 - ls.y * gx1) * inv_ls_z; sum_1 += pj1[5] * p;
-        pj2[5] = -(ls.x * gy2 - ls.y * gx2) * inv_ls_z; sum_2 += pj2[5] * p;
+        bso_jac_desc_pose(gx1, gy1, ls, pj1);
+        bso_jac_desc_pose(gx2, gy2, ls, pj2);
+        for (int q = 0; q < 6; ++q) {
+          const float p = v->p[kf_idx + q];
+          sum_1 += pj1[q] * p;
+          sum_2 += pj2[q] * p;
+        }
       }
       if (l->optimize_color_intrinsics) {
         const float g_x_1 = gx1 / color_camera->fx, g_y_1 = gy1 / color_camera->fy;
         const float g_x_2 = gx2 / color_camera->fx, g_y_2 = gy2 / color_camera->fy;
         const uint32_t c0 = l->color_intrinsics_unknown_start_index;
-        float p = v->p[c0 + 0];
-        cj1[0] = g_x_1 * bso_unproj_nx(&c->unproj, r.px); sum_1 += cj1[0] * p;
-        cj2[0] = g_x_2 * bso_unproj_nx(&c->unproj, r.px); sum_2 += cj2[0] * p;
-        p = v->p[c0 + 1];
-        cj1[1] = g_y_1 * bso_unproj_ny(&c->unproj, r.py); sum_1 += cj1[1] * p;
-        cj2[1] = g_y_2 * bso_unproj_ny(&c->unproj, r.py); sum_2 += cj2[1] * p;
-        p = v->p[c0 + 2];
-        cj1[2] = g_x_1; sum_1 += cj1[2] * p;
-        cj2[2] = g_x_2; sum_2 += cj2[2] * p;
-        p = v->p[c0 + 3];
-        cj1[3] = g_y_1; sum_1 += cj1[3] * p;
-        cj2[3] = g_y_2; sum_2 += cj2[3] * p;
+        bso_jac_desc_color_intrinsics(g_x_1, g_y_1, bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), cj1);
+        bso_jac_desc_color_intrinsics(g_x_2, g_y_2, bso_unproj_nx(&c->unproj, r.px), bso_unproj_ny(&c->unproj, r.py), cj2);
+        for (int q = 0; q < 4; ++q) {
+          const float p = v->p[c0 + q];
+          sum_1 += cj1[q] * p;
+          sum_2 += cj2[q] * p;
+        }
       }
       *v->alpha_d += sum_1 * w1 * sum_1 + sum_2 * w2 * sum_2;
       g_alpha_d64 += (double)(sum_1 * w1 * sum_1 + sum_2 * w2 * sum_2);

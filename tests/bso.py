@@ -89,6 +89,7 @@ def lib():
                                                           _BUF, C.c_int, f64p, f64p, u32p]),
         "bso_compute_cost_and_residual_count_from_images": (None, [C.c_int, C.c_int, _CAM, _CAM, C.c_float, C.c_float, _BUF, _BUF, _BUF, P(abi.Mat3x4),
                                                                    _BUF, _BUF, _BUF, C.c_int, u32p, f64p]),
+        "bso_jacobian_probe": (C.c_int, [C.c_int, C.c_int, f32p, f32p]),
         "bso_set_intrinsics_sum64": (None, [C.c_int]),
         "bso_set_literal_mode": (None, [C.c_int]),
         "bso_get_literal_mode": (C.c_int, []),
