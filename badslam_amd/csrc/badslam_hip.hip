@@ -353,7 +353,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->intr_cells.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
@@ -403,13 +403,31 @@ int bslam_profile_enable(bslam_context* ctx, int enable) {
   ctx->profiling = enable != 0;
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   ctx->prof_pending.clear();
-  for (int t = 0; t < 4; ++t) { ctx->prof_launches[t] = 0; ctx->prof_ms[t] = 0.f; }
+  for (int t = 0; t < 8; ++t) { ctx->prof_launches[t] = 0; ctx->prof_ms[t] = 0.f; }
+  for (int i = 0; i < 8; ++i) ctx->prof_counter_base[i] = 0;
+  if (ctx->prof_counters.ptr && ctx->prof_counter_slots) {
+    BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+    BSLAM_HIP_TRY(hipDeviceSynchronize());
+    BSLAM_HIP_TRY(hipMemset(ctx->prof_counters.ptr, 0, ctx->prof_counter_slots * sizeof(unsigned long long)));
+  }
+  return BSLAM_OK;
+}
+
+int bslam_profile_read_counters(bslam_context* ctx, uint64_t* counters8) {
+  if (!ctx || !counters8) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  for (int i = 0; i < 8; ++i) counters8[i] = ctx->prof_counter_base[i];
+  if (!ctx->prof_counters.ptr || !ctx->prof_counter_slots) return BSLAM_OK;
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  BSLAM_HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned long long> host(ctx->prof_counter_slots);   // [block][2]: summed here, not with contended atomics on the device
+  BSLAM_HIP_TRY(hipMemcpy(host.data(), ctx->prof_counters.ptr, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < host.size(); ++i) counters8[i & 1] += host[i];
   return BSLAM_OK;
 }
 
 int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float* total_ms) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
-  if (kernel < 0 || kernel >= 4) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown kernel tag %d", kernel);
+  if (kernel < 0 || kernel >= 8) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown kernel tag %d", kernel);
   for (auto& ev : ctx->prof_pending) {
     BSLAM_HIP_TRY(hipEventSynchronize(ev.stop));
     float ms = 0.f;
@@ -725,8 +743,24 @@ int bslam_update_surfel_activation(
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
   Schedule sc;
   if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
-  hipLaunchKernelGGL(activation_kernel, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
-                     surfel_rows_rw(surfels, active_surfels, surfels_size));
+  {
+    ProfScope prof(ctx, stream, BSLAM_PROF_ACTIVATION);
+    const size_t counter_slots = 2 * (size_t)(8u * sc.slots_per_xcd);
+    if (ctx->profiling && ctx->prof_counter_slots < counter_slots) {   // (re)size the per-block counter array, keeping what was counted so far
+      uint64_t keep[8];
+      if ((rc = bslam_profile_read_counters(ctx, keep))) return rc;
+      for (int i = 0; i < 8; ++i) ctx->prof_counter_base[i] = keep[i];
+      if ((rc = ctx->prof_counters.reserve(counter_slots * sizeof(unsigned long long)))) return rc;
+      BSLAM_HIP_TRY(hipMemsetAsync(ctx->prof_counters.ptr, 0, counter_slots * sizeof(unsigned long long), stream));
+      ctx->prof_counter_slots = counter_slots;
+    }
+    if (ctx->profiling && ctx->prof_counters.ptr)
+      hipLaunchKernelGGL(activation_kernel<true>, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
+                         surfel_rows_rw(surfels, active_surfels, surfels_size), (unsigned long long*)ctx->prof_counters.ptr);
+    else
+      hipLaunchKernelGGL(activation_kernel<false>, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
+                         surfel_rows_rw(surfels, active_surfels, surfels_size), (unsigned long long*)nullptr);
+  }
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }

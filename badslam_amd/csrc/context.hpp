@@ -147,8 +147,11 @@ struct bslam_context {
   struct ProfEntry { hipEvent_t start, stop; int tag; };
   std::vector<ProfEntry> prof_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-  int prof_launches[4] = {0, 0, 0, 0};
-  float prof_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  int prof_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float prof_ms[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bslam::Slab prof_counters; // unsigned long long[blocks][2]: work counters filled by the counting kernel variants while profiling
+  size_t prof_counter_slots = 0;
+  uint64_t prof_counter_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // counts carried over a resize of the per-block array
 };
 
 namespace bslam {

@@ -23,21 +23,39 @@ struct SurfelRowsRW {
 };
 
 // SetSurfelInactiveKernel + K x DetermineActiveSurfelsKernel (BS/kernel_surfel_activation.cu:38-79)
-__global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
+// kCount (bslam_profile_enable): additionally adds the number of (surfel, keyframe) pairs actually visited -- the walk stops at
+// the first associated active keyframe -- and the number of surfels set active to this block's two slots of `counters`
+// (counters[2 * blockIdx.x + {0, 1}]; no atomics: a single contended address would serialise 1e4..1e5 waves): what bench.py
+// credits this pass with.
+template <bool kCount>
+__global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s,
+                                                         unsigned long long* __restrict__ counters) {
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
-  if (i >= s.size) return;
-  uint8_t flag = s.active[i] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
-  const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
-  const f3 gn = unpack_normal(s.normal[i]);
-  for (int k = 0; k < kf_count; ++k) {
-    const KfDev kf = kfs[k];
-    if (kf.activation != BSLAM_KF_ACTIVE) continue;
-    Proj p;
-    if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; break; }
+  uint32_t visited = 0, activated = 0;
+  if (!kCount && i >= s.size) return;
+  if (i < s.size) {
+    uint8_t flag = s.active[i] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
+    const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
+    const f3 gn = unpack_normal(s.normal[i]);
+    for (int k = 0; k < kf_count; ++k) {
+      const KfDev kf = kfs[k];
+      if (kf.activation != BSLAM_KF_ACTIVE) continue;
+      if (kCount) visited += 1;
+      Proj p;
+      if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; activated = 1; break; }
+    }
+    s.active[i] = flag;
   }
-  s.active[i] = flag;
+  if (kCount) {
+    __shared__ uint32_t sm[2][4];
+    visited = wave_sum_u32(visited);
+    activated = wave_sum_u32(activated);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = visited; sm[1][threadIdx.x >> 6] = activated; }
+    __syncthreads();
+    if (threadIdx.x < 2) counters[2 * (size_t)blockIdx.x + threadIdx.x] += (unsigned long long)(sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+  }
 }
 
 // Mean position of every granule of 256 surfels (NaN / deleted surfels ignored): input of the

@@ -31,6 +31,8 @@ def host_lib():
     L.bsh_create.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                              f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.bsh_destroy.argtypes = [C.c_void_p]
+    L.bsh_context.restype = C.c_void_p
+    L.bsh_context.argtypes = [C.c_void_p]
     L.bsh_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, u16p, u16p, u16p, u8p, f32p]
     L.bsh_add_keyframe_from_images.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u16p, u8p, f32p]
     L.bsh_get_keyframe_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p, u16p, u16p, u8p, f32p]
@@ -208,6 +210,10 @@ class DirectBA:
         if not self._ba:
             raise DirectBAError(self.L.bsh_last_error().decode())
         self.stream = C.c_void_p(stream) if stream else C.c_void_p(None)
+
+    def context_handle(self):
+        """bslam_context* of the kernel library used by this DirectBA (for bslam_profile_*)."""
+        return C.c_void_p(self.L.bsh_context(self._ba))
 
     def _check(self, rc):
         if rc < 0:

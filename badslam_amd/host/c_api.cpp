@@ -42,6 +42,9 @@ void* bsh_create(int max_surfel_count, float raw_to_float_depth, float baseline_
 
 void bsh_destroy(void* ba) { delete static_cast<DirectBA*>(ba); }
 
+// the kernel library's context of this DirectBA (bslam_profile_* on the BA's own launches)
+void* bsh_context(void* ba) { return static_cast<DirectBA*>(ba)->context(); }
+
 int bsh_add_keyframe(void* ba_, void* stream, uint32_t frame_index, float min_depth, float max_depth, const uint16_t* depth,
                      const uint16_t* normals, const uint16_t* radius, const uint8_t* color, const float* pose7) {
   DirectBA* ba = static_cast<DirectBA*>(ba_);

@@ -111,6 +111,7 @@ class SyntheticStack:
             n = rng.uniform(-1, 1, 3)
             n[2] = -1.0
             planes.append(n / np.linalg.norm(n))
+        plane_matrix = np.stack(planes, axis=0)
         xs = (np.arange(width) - (cx - 0.5)) / fx
         ys = (np.arange(height) - (cy - 0.5)) / fy
         dxg, dyg = np.meshgrid(xs, ys)
@@ -129,17 +130,15 @@ class SyntheticStack:
             self.R.append(R)
             self.t.append(t)
             dg = dirs @ R.T
-            best = np.full((height, width), np.inf)
-            bestn = np.zeros((height, width, 3))
-            for n in planes:
-                denom = dg @ n
-                num = -(2.5 + t @ n)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    tt = num / denom
-                tt = np.where((denom < 0) & (tt > 0.3), tt, np.inf)
-                upd = tt < best
-                best = np.where(upd, tt, best)
-                bestn = np.where(upd[..., None], n[None, None, :], bestn)
+            # nearest front-facing plane per pixel, all planes at once (first plane wins ties, as a plane-by-plane sweep would)
+            denom = dg @ plane_matrix.T                                  # [h, w, planes]
+            num = -(2.5 + plane_matrix @ t)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tt = num[None, None, :] / denom
+            tt = np.where((denom < 0) & (tt > 0.3), tt, np.inf)
+            which = np.argmin(tt, axis=2)
+            best = np.take_along_axis(tt, which[..., None], axis=2)[..., 0]
+            bestn = np.where(np.isfinite(best)[..., None], plane_matrix[which], 0.0)
             valid = np.isfinite(best) & (best < 6.0)
             valid[0, :] = valid[-1, :] = False
             valid[:, 0] = valid[:, -1] = False

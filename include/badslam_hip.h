@@ -180,8 +180,12 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
  * bslam_profile_read synchronises those events and returns launches and summed ms since
  * the last enable/read. */
 int bslam_profile_enable(bslam_context* ctx, int enable);
-enum { BSLAM_PROF_POSE_ACCUMULATE = 0, BSLAM_PROF_GEOMETRY = 1, BSLAM_PROF_PCG_INIT = 2, BSLAM_PROF_PCG_STEP1 = 3 };
+enum { BSLAM_PROF_POSE_ACCUMULATE = 0, BSLAM_PROF_GEOMETRY = 1, BSLAM_PROF_PCG_INIT = 2, BSLAM_PROF_PCG_STEP1 = 3, BSLAM_PROF_ACTIVATION = 4 };
 int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float* total_ms);
+/* Work counters accumulated since bslam_profile_enable(ctx, 1) by the counting variants of the kernels (8 values, HOST out):
+ * [0] (surfel, keyframe) pairs the activation pass actually visited (it stops at a surfel's first associated active keyframe,
+ * BS/kernel_surfel_activation.cu:64-79), [1] surfels it set active, [2..7] reserved.  Synchronises the device. */
+int bslam_profile_read_counters(bslam_context* ctx, uint64_t* counters8);
 
 /* ------------------------------------------------------------------------- */
 /* Pose optimisation                                                          */

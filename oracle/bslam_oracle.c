@@ -543,23 +543,36 @@ void bso_estimate_frame_pose(
 
 #define ACTIVE(buf, i) BSO_AT(uint8_t, buf, 0, i)
 
-void bso_update_surfel_activation(
+/* visited (optional): number of (surfel, keyframe) pairs evaluated -- a surfel leaves the walk at its first associated
+ * active keyframe (bench accounting). */
+void bso_update_surfel_activation_counted(
     const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
     int keyframe_count, const bslam_keyframe_view* keyframes,
-    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels) {
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels, uint64_t* visited) {
+  if (visited) *visited = 0;
   if (surfels_size == 0) return;
   bso_unprojector unproj = bso_make_unprojector(depth_camera);
   for (uint32_t i = 0; i < surfels_size; ++i) ACTIVE(active_surfels, i) &= (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;   /* BS/kernel_surfel_activation.cu:38-46 */
+  uint64_t count = 0;
   for (int k = 0; k < keyframe_count; ++k) {
     const bslam_keyframe_view* kf = &keyframes[k];
     if (kf->activation != BSLAM_KF_ACTIVE) continue;              /* BS/kernel_surfel_activation.cc:60 */
     for (uint32_t i = 0; i < surfels_size; ++i) {                 /* BS/kernel_surfel_activation.cu:64-79 */
       if (ACTIVE(active_surfels, i) & BSLAM_SURFEL_ACTIVE_FLAG) continue;
+      ++count;
       bso_projection r;
       if (bso_surfel_projects_to_associated_pixel(i, surfels_size, surfels, &kf->depth, &kf->normals, dp, depth_camera, &unproj, &kf->frame_T_global, &r))
         ACTIVE(active_surfels, i) = BSLAM_SURFEL_ACTIVE_FLAG;
     }
   }
+  if (visited) *visited = count;
+}
+
+void bso_update_surfel_activation(
+    const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
+    int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels) {
+  bso_update_surfel_activation_counted(depth_camera, dp, keyframe_count, keyframes, surfels_size, surfels, active_surfels, NULL);
 }
 
 #define ACC(s, row, i) BSO_AT(float, s, BSLAM_SURFEL_ACCUM0 + (row), i)

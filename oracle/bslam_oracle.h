@@ -243,6 +243,15 @@ void bso_track_frame_pairwise(
     const bslam_buffer2d* base_depth_u16, const bslam_buffer2d* base_normals, const bslam_buffer2d* base_color_uchar4, int tex_mode,
     int test_different_initial_estimates, const bslam_se3f* init1, const bslam_se3f* init2, bslam_se3f* out_base_T_frame, int* iterations_per_scale);
 
+void bso_update_surfel_activation_counted(
+    const bslam_camera4f* depth_camera, const bslam_depth_params* dp, int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels, uint64_t* visited);
+/* bench.py's cpu_baseline leg (bso_bench.c) */
+int bso_bench_ba_iteration(
+    int use_depth_residuals, int use_descriptor_residuals, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
+    const bslam_depth_params* dp, int keyframe_count, const bslam_keyframe_view* keyframes,
+    uint32_t surfels_size, const bslam_buffer2d* surfels, const bslam_buffer2d* active_surfels, int tex_mode, int num_threads,
+    uint64_t* pairs3, float* Hb);
 /* point-wise Jacobian formulas (layouts in bslam_oracle.c) */
 int bso_jacobian_probe(int kind, int count, const float* in, float* out);
 /* 1: the global blocks of bso_optimize_intrinsics are float64 sums of the fp32 terms (default 0: serial fp32) */

@@ -94,6 +94,8 @@ def lib():
         "bso_set_literal_mode": (None, [C.c_int]),
         "bso_get_literal_mode": (C.c_int, []),
         "bso_association_margins": (None, [_CAM, _DP, _KFS, C.c_uint32, _BUF, f64p]),
+        "bso_bench_ba_iteration": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, _BUF, C.c_int, C.c_int,
+                                             P(C.c_uint64), f32p]),
         "bso_bench_pose_pass": (C.c_int, [C.c_int, C.c_int, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, C.c_int, f32p, u32p, C.c_int]),
     }
     for name, (res, args) in sig.items():
