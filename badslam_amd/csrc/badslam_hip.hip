@@ -491,9 +491,9 @@ int bslam_debug_decode_normals(bslam_context* ctx, void* stream_, float* out_xyz
 
 int bslam_debug_jacobians(bslam_context* ctx, void* stream_, int kind, int count, const float* in, float* out) {
   hipStream_t stream = (hipStream_t)stream_;
-  static const int kIn[7] = {10, 1, 21, 11, 14, 8, 10}, kOut[7] = {7, 1, 7, 9, 1, 4, 7};
+  static const int kIn[8] = {10, 1, 21, 11, 14, 8, 10, 1}, kOut[8] = {7, 1, 7, 9, 1, 4, 7, 2};
   if (!ctx || !in || !out) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
-  if (kind < 0 || kind > 6) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown probe kind %d", kind);
+  if (kind < 0 || kind > 7) return fail(BSLAM_ERR_INVALID_ARGUMENT, "unknown probe kind %d", kind);
   if (count <= 0) return BSLAM_OK;
   BSLAM_HIP_TRY(hipSetDevice(ctx->device));
   const size_t in_bytes = (size_t)count * kIn[kind] * sizeof(float), out_bytes = (size_t)count * kOut[kind] * sizeof(float);

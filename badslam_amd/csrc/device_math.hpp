@@ -93,10 +93,31 @@ __device__ __forceinline__ float ny_of(const CamConsts& c, float py) { return __
 __device__ __forceinline__ f3 unproject(const CamConsts& c, int x, int y, float depth) {                    // BS/surfel_projection.cuh:110
   return mk3(depth * nx_of(c, (float)x), depth * ny_of(c, (float)y), depth);
 }
+// Correctly rounded 1 / x for 2^-96 < |x| < 2^96: the compiler's expansion of an IEEE division (v_div_scale x 2, v_rcp, four
+// fmas, a multiply, v_div_fmas, v_div_fixup) with the parts that only serve numerators != 1, denormal scaling and special
+// operands removed -- the same v_rcp seed and the same fma chain, so the same bits as 1.0f / x there, in 7 instead of 11
+// instructions.  (tests/test_gpu_parity.py::test_midrange_reciprocal_is_correctly_rounded sweeps it against 1.0f / x.)
+#ifndef BSLAM_RCP_MIDRANGE
+#define BSLAM_RCP_MIDRANGE 1
+#endif
+__device__ __forceinline__ float rcp_rn_midrange(float x) {
+#if BSLAM_RCP_MIDRANGE
+  const float r0 = __builtin_amdgcn_rcpf(x);
+  const float e0 = __builtin_fmaf(-x, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float e1 = __builtin_fmaf(-x, r1, 1.0f);
+  const float r2 = __builtin_fmaf(e1, r1, r1);
+  const float e2 = __builtin_fmaf(-x, r2, 1.0f);
+  return __builtin_fmaf(e2, r1, r2);
+#else
+  return 1.0f / x;
+#endif
+}
+
 __device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3 p) {                       // BS/surfel_projection.cuh:52
   // one correctly rounded reciprocal + two multiplies (the CPU oracle's projection has the same shape; the reference's
   // -use_fast_math build evaluates p.x / p.z as p.x * rcp(p.z))
-  const float inv_z = 1.0f / p.z;
+  const float inv_z = rcp_rn_midrange(p.z);
   return f2{__builtin_fmaf(fx, p.x * inv_z, cx), __builtin_fmaf(fy, p.y * inv_z, cy)};
 }
 
@@ -193,7 +214,7 @@ __device__ __forceinline__ float srcp(float b) { return __builtin_amdgcn_rcpf(b)
 __device__ __forceinline__ float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #else
 __device__ __forceinline__ float sdiv(float a, float b) { return a / b; }
-__device__ __forceinline__ float srcp(float b) { return 1.0f / b; }
+__device__ __forceinline__ float srcp(float b) { return rcp_rn_midrange(b); }
 __device__ __forceinline__ float ssqrt(float x) { return sqrtf(x); }
 #endif
 
@@ -263,22 +284,29 @@ __device__ __forceinline__ LumaQuad unpack_quad(uint32_t q) {
 
 // i in [-1, w-1], j in [-1, h-1]
 __device__ __forceinline__ uint32_t quad_at(const KfDev& kf, const CamConsts& c, int i, int j) {
-  return gload(kf.quads + (size_t)(j + 1) * (size_t)(c.color_width + 1) + (size_t)(i + 1));
+  // offset inside one keyframe's table: < 2^24, 32-bit arithmetic (v_mad_u32_u24) on top of the uniform base
+  return gload(kf.quads + (__umul24((uint32_t)(j + 1), (uint32_t)(c.color_width + 1)) + (uint32_t)(i + 1)));
 }
 
 // Bilinear footprint of a sample at pixel-corner coordinates (x, y): base texel (clamped to the quad
 // table's range, which reproduces clamp addressing exactly) and the two filter weights.
-struct TexFootprint { int i, j; float a, b; };
+struct TexFootprint {
+  int i, j;
+  float a, b;        // filter weights (quantised to 1/256 in the fixed-point texture mode)
+  float ua, ub;      // the unquantised fractions
+  bool interior;     // 0 <= x - 0.5 < w - 1 and 0 <= y - 0.5 < h - 1: no clamping anywhere in the 2x2 footprint
+};
 __device__ __forceinline__ TexFootprint tex_footprint(const CamConsts& c, float x, float y) {
   const float xb = x - 0.5f, yb = y - 0.5f;
   const float fx = floorf(xb), fy = floorf(yb);
   TexFootprint f;
-  f.a = xb - fx;
-  f.b = yb - fy;
+  f.a = f.ua = xb - fx;
+  f.b = f.ub = yb - fy;
   if (c.tex_mode == BSLAM_TEX_FIXED_POINT_1_8) {
     f.a = floorf(f.a * 256.0f + 0.5f) * (1.0f / 256.0f);
     f.b = floorf(f.b * 256.0f + 0.5f) * (1.0f / 256.0f);
   }
+  f.interior = xb >= 0.f && yb >= 0.f && xb < (float)(c.color_width - 1) && yb < (float)(c.color_height - 1);
   // clamp = v_med3_f32 (same selection as fminf(fmaxf(.)) for the finite arguments that reach this point, without the
   // two NaN-quieting moves fminf / fmaxf cost each)
   f.i = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, (float)(c.color_width - 1));
@@ -292,9 +320,36 @@ __device__ __forceinline__ float tex_filter(const LumaQuad& t, float a, float b)
   const float w11 = a * b;
   return ((w00 * t.tl + w10 * t.tr) + w01 * t.bl) + w11 * t.br;
 }
-__device__ __forceinline__ float tex_w(const KfDev& kf, const CamConsts& c, float x, float y) {
+// Sampling arithmetic of the RESIDUAL path (descriptor residual and its image gradient; colours and downsampled images, whose
+// outputs are integers, keep tex_filter above):
+//   - texels stay raw bytes 0..255 (exact in fp32, and so are their differences); the 1 / 255 normalisation is folded into the
+//     residual's intensity scale, 180 * (i1 - i0) = (180 / 255) * (b1 - b0);
+//   - the bilinear value is a nested interpolation with explicit fused multiply-adds (3 roundings instead of 11), the gradient
+//     one fma per component (1 rounding each).
+// The CPU checker evaluates the same sequences, so the two agree to the bit; the reference's formula as written is its
+// "literal" mode.
+constexpr float kDescScale = 180.f / 255.f;
+__device__ __forceinline__ LumaQuad unpack_quad_bytes(uint32_t q) {
+  LumaQuad r;
+  r.tl = (float)(q & 0xffu);
+  r.tr = (float)((q >> 8) & 0xffu);
+  r.bl = (float)((q >> 16) & 0xffu);
+  r.br = (float)(q >> 24);
+  return r;
+}
+__device__ __forceinline__ float bilinear_bytes(const LumaQuad& t, float a, float b) {
+  const float top = __builtin_fmaf(a, t.tr - t.tl, t.tl);
+  const float bot = __builtin_fmaf(a, t.br - t.bl, t.bl);
+  return __builtin_fmaf(b, bot - top, top);
+}
+__device__ __forceinline__ void bilinear_gradient_bytes(const LumaQuad& t, float tx, float ty, float* dx, float* dy) {
+  *dx = __builtin_fmaf(ty, (t.br - t.bl) - (t.tr - t.tl), t.tr - t.tl);
+  *dy = __builtin_fmaf(tx, (t.br - t.tr) - (t.bl - t.tl), t.bl - t.tl);
+}
+// bilinear luma in byte units at pixel-corner coordinates (x, y)
+__device__ __forceinline__ float tex_b(const KfDev& kf, const CamConsts& c, float x, float y) {
   const TexFootprint f = tex_footprint(c, x, y);
-  return tex_filter(unpack_quad(quad_at(kf, c, f.i, f.j)), f.a, f.b);
+  return bilinear_bytes(unpack_quad_bytes(quad_at(kf, c, f.i, f.j)), f.a, f.b);
 }
 
 // BS/cost_function.cuh:115-136
@@ -323,11 +378,11 @@ __device__ __forceinline__ void tangent_projections(f3 gp, f3 gn, float radius_s
 
 // BS/cost_function.cuh:140-156
 __device__ __forceinline__ void raw_descriptor_residual(const KfDev& kf, const CamConsts& c, f2 pxy, f2 t1, f2 t2, float d1, float d2, float* r1, float* r2) {
-  const float intensity = tex_w(kf, c, pxy.x, pxy.y);
-  const float i1 = tex_w(kf, c, t1.x, t1.y);
-  const float i2 = tex_w(kf, c, t2.x, t2.y);
-  *r1 = (180.f * (i1 - intensity)) - d1;
-  *r2 = (180.f * (i2 - intensity)) - d2;
+  const float b0 = tex_b(kf, c, pxy.x, pxy.y);
+  const float b1 = tex_b(kf, c, t1.x, t1.y);
+  const float b2 = tex_b(kf, c, t2.x, t2.y);
+  *r1 = __builtin_fmaf(kDescScale, b1 - b0, -d1);
+  *r2 = __builtin_fmaf(kDescScale, b2 - b0, -d2);
 }
 
 // one block of BS/cost_function.cuh:200-239: base texel and weights of the gradient at p
@@ -343,73 +398,58 @@ __device__ __forceinline__ GradFootprint grad_footprint(const CamConsts& c, f2 p
   g.iy = min(g.iy, c.color_height - 1);
   return g;
 }
+// the reference's formula as written, on texels in [0, 1] (bslam_debug_jacobians compares it with the fma form above)
 __device__ __forceinline__ void grad_filter(const LumaQuad& t, const GradFootprint& g, float* dx, float* dy) {
   *dx = (t.br - t.bl) * g.ty + (t.tr - t.tl) * (1 - g.ty);
   *dy = (t.br - t.tr) * g.tx + (t.bl - t.tl) * (1 - g.tx);
 }
-__device__ __forceinline__ void point_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* dx, float* dy) {
-  const GradFootprint g = grad_footprint(c, p);
-  grad_filter(unpack_quad(quad_at(kf, c, g.ix, g.iy)), g, dx, dy);
-}
 
-// BS/cost_function.cuh:191-254 (without the three dead fetches :241-243)
-__device__ __forceinline__ void descriptor_jacobian_wrt_projected_position(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2,
-                                                                           float* gx1, float* gy1, float* gx2, float* gy2) {
-  float cdx, cdy, t1dx, t1dy, t2dx, t2dy;
-  point_gradient(kf, c, cp, &cdx, &cdy);
-  point_gradient(kf, c, t1, &t1dx, &t1dy);
-  point_gradient(kf, c, t2, &t2dx, &t2dy);
-  *gx1 = 180.f * (t1dx - cdx);
-  *gy1 = 180.f * (t1dy - cdy);
-  *gx2 = 180.f * (t2dx - cdx);
-  *gy2 = 180.f * (t2dy - cdy);
-}
-
-// Bilinear value and gradient at p from one gather: the sample's quad doubles as the gradient's
-// whenever both footprints start at the same texel (always, except in the half-pixel border strip).
-__device__ __forceinline__ void point_value_and_gradient(const KfDev& kf, const CamConsts& c, f2 p, float* value, float* dx, float* dy) {
-  const TexFootprint f = tex_footprint(c, p.x, p.y);
-  const GradFootprint g = grad_footprint(c, p);
-  const LumaQuad t = unpack_quad(quad_at(kf, c, f.i, f.j));
-  LumaQuad tg = t;
-  if (g.ix != f.i || g.iy != f.j) tg = unpack_quad(quad_at(kf, c, g.ix, g.iy));   // only in the half-pixel border strip
-  *value = tex_filter(t, f.a, f.b);
-  grad_filter(tg, g, dx, dy);
-}
-
-// raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers
-__device__ __forceinline__ void descriptor_residual_and_jacobian(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2, float d1, float d2,
-                                                                 float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
-  // The three footprints first, then the three gathers back to back (one wait instead of three dependent
-  // load -> wait -> filter rounds), then the filters: same arithmetic as three point_value_and_gradient calls.
-  const f2 pts[3] = {cp, t1, t2};
+// raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers, in two steps: the three
+// footprints and the three gathers first (DescSamples: the loads are in flight when it returns), the filters later -- so
+// that a kernel can issue the gathers of several surfels before it waits for the first.
+struct DescSamples {
   TexFootprint f[3];
   GradFootprint g[3];
   uint32_t q[3];
+};
+__device__ __forceinline__ DescSamples descriptor_samples_issue(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2) {
+  DescSamples d;
+  const f2 pts[3] = {cp, t1, t2};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    f[k] = tex_footprint(c, pts[k].x, pts[k].y);
-    g[k] = grad_footprint(c, pts[k]);
+    d.f[k] = tex_footprint(c, pts[k].x, pts[k].y);
+    // Inside the image the gradient's footprint (BS/cost_function.cuh:200-211: ix = int(max(0, x - 0.5)), tx = clamp(x - 0.5 - ix, 0, 1))
+    // IS the sample's: ix = floor(x - 0.5) and tx = the unquantised fraction, bit for bit (the same subtraction); only the
+    // half-pixel border strip needs the general form.
+    d.g[k].ix = d.f[k].i; d.g[k].iy = d.f[k].j; d.g[k].tx = d.f[k].ua; d.g[k].ty = d.f[k].ub;
+    if (!d.f[k].interior) d.g[k] = grad_footprint(c, pts[k]);
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) q[k] = quad_at(kf, c, f[k].i, f[k].j);
-  float val[3], gx[3], gy[3];
+  for (int k = 0; k < 3; ++k) d.q[k] = quad_at(kf, c, d.f[k].i, d.f[k].j);
+  return d;
+}
+__device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const CamConsts& c, const DescSamples& d, float d1, float d2,
+                                                          float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
+  float val[3], gx[3], gy[3];   // byte units
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const LumaQuad t = unpack_quad(q[k]);
+    const LumaQuad t = unpack_quad_bytes(d.q[k]);
     LumaQuad tg = t;
-    if (g[k].ix != f[k].i || g[k].iy != f[k].j) tg = unpack_quad(quad_at(kf, c, g[k].ix, g[k].iy));   // only in the half-pixel border strip
-    val[k] = tex_filter(t, f[k].a, f[k].b);
-    grad_filter(tg, g[k], &gx[k], &gy[k]);
+    if (d.g[k].ix != d.f[k].i || d.g[k].iy != d.f[k].j) tg = unpack_quad_bytes(quad_at(kf, c, d.g[k].ix, d.g[k].iy));   // only in the half-pixel border strip
+    val[k] = bilinear_bytes(t, d.f[k].a, d.f[k].b);
+    bilinear_gradient_bytes(tg, d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
   }
-  const float intensity = val[0], i1 = val[1], i2 = val[2];
-  const float cdx = gx[0], cdy = gy[0], t1dx = gx[1], t1dy = gy[1], t2dx = gx[2], t2dy = gy[2];
-  *r1 = (180.f * (i1 - intensity)) - d1;
-  *r2 = (180.f * (i2 - intensity)) - d2;
-  *gx1 = 180.f * (t1dx - cdx);
-  *gy1 = 180.f * (t1dy - cdy);
-  *gx2 = 180.f * (t2dx - cdx);
-  *gy2 = 180.f * (t2dy - cdy);
+  *r1 = __builtin_fmaf(kDescScale, val[1] - val[0], -d1);
+  *r2 = __builtin_fmaf(kDescScale, val[2] - val[0], -d2);
+  *gx1 = kDescScale * (gx[1] - gx[0]);
+  *gy1 = kDescScale * (gy[1] - gy[0]);
+  *gx2 = kDescScale * (gx[2] - gx[0]);
+  *gy2 = kDescScale * (gy[2] - gy[0]);
+}
+__device__ __forceinline__ void descriptor_residual_and_jacobian(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2, float d1, float d2,
+                                                                 float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
+  const DescSamples d = descriptor_samples_issue(kf, c, cp, t1, t2);
+  descriptor_samples_finish(kf, c, d, d1, d2, r1, r2, gx1, gy1, gx2, gy2);
 }
 
 // BS/surfel_projection.cuh:196-207
@@ -470,22 +510,30 @@ __global__ __launch_bounds__(256) void build_quads_kernel(CamConsts c, const KfD
   quads[((size_t)k * (h + 1) + qy) * (size_t)(w + 1) + qx] = tl | (tr << 8) | (bl << 16) | (br << 24);
 }
 
-// gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
-// associated with the pixel it projects to.
-__device__ __forceinline__ bool project_and_associate(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, Proj* r) {
+// Projection + association in three stages, so that a kernel can put the record gathers of several surfels in flight before
+// it consumes the first (project_and_associate below is their composition; same arithmetic either way).
+// Stage 1: MultiplyIfResultZIsPositive BS/cuda_matrix.cuh:113-124 + ProjectSurfelToImage BS/util.cuh:86-99.  True when the
+// surfel projects into the image; fills local, pxy, px, py.
+__device__ __forceinline__ bool project_to_pixel(const CamConsts& c, const KfDev& kf, f3 gp, Proj* r) {
   const M34& T = kf.frame_T_global;
-  // MultiplyIfResultZIsPositive BS/cuda_matrix.cuh:113-124
   r->local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
   if (r->local.z <= 0.f) return false;
   r->local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
   r->local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
-  // ProjectSurfelToImage BS/util.cuh:86-99
   r->pxy = project(c.fx, c.fy, c.cx, c.cy, r->local);
   r->px = f2i(r->pxy.x);
   r->py = f2i(r->pxy.y);
-  if (r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height) return false;
-  // IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127
-  const uint2 rec = gload_u2(kf.records + ((size_t)r->py * c.width + r->px));
+  return !(r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height);
+}
+// Stage 2: the pixel's derived record.  The offset inside one keyframe's table fits 24 bits (v_mad_u32_u24, full rate) and is
+// added to the uniform base as a 32-bit offset (global_load with an SGPR base): no 64-bit vector arithmetic per gather.
+__device__ __forceinline__ uint2 load_record(const CamConsts& c, const KfDev& kf, const Proj& r) {
+  const uint32_t idx = __umul24((uint32_t)r.py, (uint32_t)c.width) + (uint32_t)r.px;
+  return gload_u2(kf.records + idx);
+}
+// Stage 3: IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127 on the loaded record.
+__device__ __forceinline__ bool associate_with_record(const CamConsts& c, const KfDev& kf, f3 gn, uint2 rec, Proj* r) {
+  const M34& T = kf.frame_T_global;
   if (rec.y & ((uint32_t)BSLAM_INVALID_DEPTH_BIT << 16)) return false;
   r->depth = __uint_as_float(rec.x);
   r->raw_depth = rec.y >> 16;
@@ -503,6 +551,12 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
   const f3 pn = u16_to_image_space_normal(r->pixel_normal);
   if (dot(r->n_local, pn) < kCosNormalCompat) return false;
   return true;
+}
+// gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
+// associated with the pixel it projects to.
+__device__ __forceinline__ bool project_and_associate(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, Proj* r) {
+  if (!project_to_pixel(c, kf, gp, r)) return false;
+  return associate_with_record(c, kf, gn, load_record(c, kf, *r), r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,6 +722,24 @@ __device__ __forceinline__ float dpp_add_xor1(float keep, float send) {   // qua
 }
 __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   const uint32_t lane = threadIdx.x & 63u;
+#ifndef BSLAM_TR_PERMLANE
+#define BSLAM_TR_PERMLANE 0
+#endif
+#if BSLAM_TR_PERMLANE
+  // v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b; v_permlane16_swap: the odd rows of 16 lanes of a <-> the
+  // even rows of b.  After swapping v[i] with v[i + N], a + b is "own kept value + partner's sent value" in every lane:
+  // two instructions per exchange instead of two selects, a ds_bpermute and an add.
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#else
 #define BSLAM_TR_STEP(N, MASK)                                           \
   {                                                                      \
     const bool up = (lane & MASK) != 0;                                  \
@@ -680,6 +752,7 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   BSLAM_TR_STEP(16, 32)
   BSLAM_TR_STEP(8, 16)
 #undef BSLAM_TR_STEP
+#endif
   {
     const bool up = (lane & 8u) != 0;
 #pragma unroll

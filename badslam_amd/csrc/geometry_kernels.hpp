@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void jacobian_probe_kernel(int kind, int count
     for (int k = 0; k < 6; ++k) o[1 + k] = J[k];
   } else if (kind == 1) {
     o[0] = depth_position_jacobian(a[0]);
+  } else if (kind == 7) {
+    o[0] = rcp_rn_midrange(a[0]);
+    o[1] = 1.0f / a[0];
   } else if (kind == 2) {
     const float m[12] = {a[9], a[10], a[11], 0, a[12], a[13], a[14], 0, 0, 0, 0, 0};
     float dj[6];
@@ -166,13 +169,11 @@ __global__ __launch_bounds__(256) void jacobian_probe_kernel(int kind, int count
     for (int k = 0; k < 6; ++k) o[1 + k] = dj[k];
   } else {
     const LumaQuad q{a[0], a[1], a[2], a[3]};
-    GradFootprint g;
-    g.ix = g.iy = 0; g.tx = a[4]; g.ty = a[5];
     float dx, dy;
-    grad_filter(q, g, &dx, &dy);
+    bilinear_gradient_bytes(q, a[4], a[5], &dx, &dy);   // the residual path's forms (scale-agnostic: any texel unit)
     if (kind == 3) {
       float J[6];
-      o[0] = tex_filter(q, a[4], a[5]);
+      o[0] = bilinear_bytes(q, a[4], a[5]);
       o[1] = dx * a[6];
       o[2] = dy * a[7];
       descriptor_pose_jacobian(o[1], o[2], mk3(a[8], a[9], a[10]), J);

@@ -365,6 +365,7 @@ int bslam_debug_pose_residuals(
  *   kind 4 descriptor / position [tl, tr, bl, br, tx, ty, fx, fy, rn(3), ls(3)]                -> [j]
  *   kind 5 descriptor / colour intrinsics [tl, tr, bl, br, tx, ty, nx, ny]                      -> [j(4)]
  *   kind 6 = kind 0 in the pose kernel's fused-multiply-add form
+ *   kind 7 arithmetic check  [x] -> [the kernels' 7-instruction correctly rounded reciprocal of x, 1.0f / x]
  * (tl .. br = the 2x2 texel footprint in [0, 1], tx, ty = fractional offsets of the sample).  tests/test_gpu_jacobians.py holds
  * these to the values of the reference's symbolic derivation (applications/badslam/scripts/jacobians_derivation.py). */
 int bslam_debug_jacobians(bslam_context* ctx, void* stream, int kind, int count, const float* in, float* out);

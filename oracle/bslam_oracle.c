@@ -354,6 +354,11 @@ void bso_association_margins(const bslam_camera4f* depth_camera, const bslam_dep
  *   kind 4 descriptor / position [tl, tr, bl, br, tx, ty, fx, fy, rn(3), ls(3)]                           -> [j]
  *   kind 5 descriptor / colour intrinsics [tl, tr, bl, br, tx, ty, nx, ny]                                 -> [j(4)]
  * (tl .. br = the 2x2 texel footprint, tx, ty = fractional offsets of the sample inside it). */
+static void probe_gradient(const float* a, float* dx, float* dy) {   /* the gradient form of the active evaluation shape */
+  if (bso_literal_mode) bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], dx, dy);
+  else bso_bilinear_gradient_bytes(a[0], a[1], a[2], a[3], a[4], a[5], dx, dy);
+}
+
 int bso_jacobian_probe(int kind, int count, const float* in, float* out) {
   static const int kIn[6] = {10, 1, 21, 11, 14, 8}, kOut[6] = {7, 1, 7, 9, 1, 4};
   if (kind < 0 || kind > 5) return -1;
@@ -376,9 +381,10 @@ int bso_jacobian_probe(int kind, int count, const float* in, float* out) {
       }
       case 3: {
         float dx, dy;
-        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        probe_gradient(a, &dx, &dy);
         const float w00 = (1.0f - a[4]) * (1.0f - a[5]), w10 = a[4] * (1.0f - a[5]), w01 = (1.0f - a[4]) * a[5], w11 = a[4] * a[5];
-        o[0] = ((w00 * a[0] + w10 * a[1]) + w01 * a[2]) + w11 * a[3];       /* the filter of bso_tex_w */
+        o[0] = bso_literal_mode ? ((w00 * a[0] + w10 * a[1]) + w01 * a[2]) + w11 * a[3]       /* the filter of bso_tex_w */
+                                : bso_bilinear_bytes(a[0], a[1], a[2], a[3], a[4], a[5]);
         o[1] = dx * a[6];
         o[2] = dy * a[7];
         bso_jac_desc_pose(o[1], o[2], bso_make3(a[8], a[9], a[10]), o + 3);
@@ -386,13 +392,13 @@ int bso_jacobian_probe(int kind, int count, const float* in, float* out) {
       }
       case 4: {
         float dx, dy;
-        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        probe_gradient(a, &dx, &dy);
         o[0] = bso_jac_desc_position(dx, dy, a[6], a[7], bso_make3(a[8], a[9], a[10]), bso_make3(a[11], a[12], a[13]));
         break;
       }
       case 5: {
         float dx, dy;
-        bso_bilinear_gradient(a[0], a[1], a[2], a[3], a[4], a[5], &dx, &dy);
+        probe_gradient(a, &dx, &dy);
         bso_jac_desc_color_intrinsics(dx, dy, a[6], a[7], o);
         break;
       }

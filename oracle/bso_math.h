@@ -395,6 +395,45 @@ static inline float bso_texel_w(const bslam_buffer2d* color, int ix, int iy) {
   const uint8_t* px = (const uint8_t*)color->address + (size_t)iy * color->pitch + 4 * (size_t)ix;
   return px[3] * (1.0f / 255.0f);
 }
+/* Twin shape of the sampling arithmetic (shared with csrc/device_math.hpp; the literal shape is the CUDA programming guide's
+ * formula as written, above and in bso_tex_w / bso_point_gradient below):
+ *   - texels stay raw bytes 0..255 (exact in fp32; their differences are exact too) and the 1 / 255 normalisation is folded
+ *     into the residual's intensity scale: 180 * (i1 - i0) = (180 / 255) * (b1 - b0);
+ *   - bilinear value as nested interpolation with explicit fused multiply-adds: top = a (tr - tl) + tl, bot = a (br - bl) + bl,
+ *     value = b (bot - top) + top  (3 roundings instead of 11);
+ *   - gradient dx = ty ((br - bl) - (tr - tl)) + (tr - tl), dy = tx ((br - tr) - (bl - tl)) + (bl - tl)  (1 rounding each).
+ * Only the residual path (descriptor residual and its image gradient) takes this shape; colours and downsampled images,
+ * whose outputs are integers, keep the literal filter in both modes. */
+#define BSO_DESC_SCALE (180.f / 255.f)
+static inline float bso_texel_b(const bslam_buffer2d* color, int ix, int iy) {     /* luma byte 0..255, clamp addressing */
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix > color->width - 1) ix = color->width - 1;
+  if (iy > color->height - 1) iy = color->height - 1;
+  return (float)((const uint8_t*)color->address + (size_t)iy * color->pitch + 4 * (size_t)ix)[3];
+}
+static inline float bso_quantise_weight(float a, int mode) {
+  if (mode != BSLAM_TEX_FIXED_POINT_1_8) return a;
+  return floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+}
+static inline float bso_bilinear_bytes(float tl, float tr, float bl, float br, float a, float b) {
+  const float top = BSO_FMA(a, tr - tl, tl);
+  const float bot = BSO_FMA(a, br - bl, bl);
+  return BSO_FMA(b, bot - top, top);
+}
+static inline void bso_bilinear_gradient_bytes(float tl, float tr, float bl, float br, float tx, float ty, float* dx, float* dy) {
+  *dx = BSO_FMA(ty, (br - bl) - (tr - tl), tr - tl);
+  *dy = BSO_FMA(tx, (br - tr) - (bl - tl), bl - tl);
+}
+/* twin: bilinear luma in BYTE units at pixel-corner coordinates (x, y) */
+static inline float bso_tex_b(const bslam_buffer2d* color, float x, float y, int mode) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = bso_quantise_weight(xb - fx, mode), b = bso_quantise_weight(yb - fy, mode);
+  const int i = (int)fminf(fmaxf(fx, -2.0f), (float)color->width);
+  const int j = (int)fminf(fmaxf(fy, -2.0f), (float)color->height);
+  return bso_bilinear_bytes(bso_texel_b(color, i, j), bso_texel_b(color, i + 1, j), bso_texel_b(color, i, j + 1), bso_texel_b(color, i + 1, j + 1), a, b);
+}
 static inline float bso_tex_w(const bslam_buffer2d* color, float x, float y, int mode) {
   const float xb = x - 0.5f;
   const float yb = y - 0.5f;
@@ -402,10 +441,9 @@ static inline float bso_tex_w(const bslam_buffer2d* color, float x, float y, int
   const float fy = floorf(yb);
   float a = xb - fx;
   float b = yb - fy;
-  if (mode == BSLAM_TEX_FIXED_POINT_1_8) {
-    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
-    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
-  }
+  if (!BSO_LITERAL) return bso_tex_b(color, x, y, mode) * (1.0f / 255.0f);
+  a = bso_quantise_weight(a, mode);
+  b = bso_quantise_weight(b, mode);
   /* clamp in float first so that huge coordinates cannot overflow the int conversion */
   const float fxc = fminf(fmaxf(fx, -2.0f), (float)color->width);
   const float fyc = fminf(fmaxf(fy, -2.0f), (float)color->height);
@@ -437,6 +475,12 @@ static inline void bso_tangent_projections(bso_f3 gp, bso_f3 gn, float radius_sq
 /* BS/cost_function.cuh:140-156 */
 static inline void bso_raw_descriptor_residual(const bslam_buffer2d* color, int tex_mode, bso_f2 pxy, bso_f2 t1, bso_f2 t2,
                                                float d1, float d2, float* r1, float* r2) {
+  if (!BSO_LITERAL) {
+    const float b0 = bso_tex_b(color, pxy.x, pxy.y, tex_mode), b1 = bso_tex_b(color, t1.x, t1.y, tex_mode), b2 = bso_tex_b(color, t2.x, t2.y, tex_mode);
+    *r1 = BSO_FMA(BSO_DESC_SCALE, b1 - b0, -d1);
+    *r2 = BSO_FMA(BSO_DESC_SCALE, b2 - b0, -d2);
+    return;
+  }
   float intensity = bso_tex_w(color, pxy.x, pxy.y, tex_mode);
   float t1_intensity = bso_tex_w(color, t1.x, t1.y, tex_mode);
   float t2_intensity = bso_tex_w(color, t2.x, t2.y, tex_mode);
@@ -455,6 +499,11 @@ static inline void bso_point_gradient(const bslam_buffer2d* color, bso_f2 p, flo
   /* clamp before the +1 so that a saturated index cannot overflow (same texels as clamp addressing) */
   if (ix > color->width - 1) ix = color->width - 1;
   if (iy > color->height - 1) iy = color->height - 1;
+  if (!BSO_LITERAL) {   /* twin: gradient in BYTE units per pixel (bso_descriptor_jacobian_wrt_projected_position applies 180 / 255) */
+    bso_bilinear_gradient_bytes(bso_texel_b(color, ix, iy), bso_texel_b(color, ix + 1, iy), bso_texel_b(color, ix, iy + 1), bso_texel_b(color, ix + 1, iy + 1),
+                                tx, ty, dx, dy);
+    return;
+  }
   float top_left = bso_texel_w(color, ix, iy);
   float top_right = bso_texel_w(color, ix + 1, iy);
   float bottom_left = bso_texel_w(color, ix, iy + 1);
@@ -469,10 +518,11 @@ static inline void bso_descriptor_jacobian_wrt_projected_position(const bslam_bu
   bso_point_gradient(color, c, &cdx, &cdy);
   bso_point_gradient(color, t1, &t1dx, &t1dy);
   bso_point_gradient(color, t2, &t2dx, &t2dy);
-  *gx1 = 180.f * (t1dx - cdx);
-  *gy1 = 180.f * (t1dy - cdy);
-  *gx2 = 180.f * (t2dx - cdx);
-  *gy2 = 180.f * (t2dy - cdy);
+  const float scale = BSO_LITERAL ? 180.f : BSO_DESC_SCALE;   /* the twin's gradients are in byte units */
+  *gx1 = scale * (t1dx - cdx);
+  *gy1 = scale * (t1dy - cdy);
+  *gx2 = scale * (t2dx - cdx);
+  *gy2 = scale * (t2dy - cdy);
 }
 
 /* ---- association (BS/surfel_projection_nvcc_only.cuh:49-127, 302-332) ---------- */

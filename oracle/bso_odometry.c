@@ -38,6 +38,22 @@ static float tex_u8(const bslam_buffer2d* img, float x, float y, int mode) {
   const float t00 = texel_u8(img, i, j), t10 = texel_u8(img, i + 1, j), t01 = texel_u8(img, i, j + 1), t11 = texel_u8(img, i + 1, j + 1);
   return (((1.0f - a) * (1.0f - b) * t00 + a * (1.0f - b) * t10) + (1.0f - a) * b * t01) + a * b * t11;
 }
+/* twin shape of the residual's sampling (bso_math.h): byte units, nested fma interpolation */
+static float texel_u8_b(const bslam_buffer2d* img, int ix, int iy) {
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (ix > img->width - 1) ix = img->width - 1;
+  if (iy > img->height - 1) iy = img->height - 1;
+  return (float)BSO_AT(uint8_t, img, iy, ix);
+}
+static float tex_u8_b(const bslam_buffer2d* img, float x, float y, int mode) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = bso_quantise_weight(xb - fx, mode), b = bso_quantise_weight(yb - fy, mode);
+  const int i = (int)fminf(fmaxf(fx, -2.0f), (float)img->width);
+  const int j = (int)fminf(fmaxf(fy, -2.0f), (float)img->height);
+  return bso_bilinear_bytes(texel_u8_b(img, i, j), texel_u8_b(img, i + 1, j), texel_u8_b(img, i, j + 1), texel_u8_b(img, i + 1, j + 1), a, b);
+}
 static uint8_t to_u8(float v) { return (uint8_t)(v >= 255.f ? 255 : (v <= 0.f || v != v ? 0 : (int)v)); }   /* cvt.rzi.u8.f32 saturates */
 
 /* ComputeBrightnessKernel(texture) BS/cuda_image_processing.cu:196-205: luma of the uchar4 keyframe colour image */
@@ -129,6 +145,10 @@ static void point_gradient_u8(const bslam_buffer2d* img, bso_f2 p, float* dx, fl
   const float ty = fmaxf(0.f, fminf(1.f, p.y - 0.5f - iy));
   if (ix > img->width - 1) ix = img->width - 1;
   if (iy > img->height - 1) iy = img->height - 1;
+  if (!BSO_LITERAL) {   /* byte units; the caller applies 180 / 255 */
+    bso_bilinear_gradient_bytes(texel_u8_b(img, ix, iy), texel_u8_b(img, ix + 1, iy), texel_u8_b(img, ix, iy + 1), texel_u8_b(img, ix + 1, iy + 1), tx, ty, dx, dy);
+    return;
+  }
   const float tl = texel_u8(img, ix, iy), tr = texel_u8(img, ix + 1, iy), bl = texel_u8(img, ix, iy + 1), br = texel_u8(img, ix + 1, iy + 1);
   *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
   *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
@@ -184,15 +204,22 @@ static void evaluate_pixel(int x, int y, int use_depth, int use_desc, int need_j
       bso_f2 c0, c1, c2;
       if (visible && x1_local.z > 0 && y1_local.z > 0 && bso_depth_to_color_pxy(pxy, &d2c, &c0) && bso_depth_to_color_pxy(pxy_t1, &d2c, &c1) &&
           bso_depth_to_color_pxy(pxy_t2, &d2c, &c2)) {
-        const float i0 = tex_u8(frame_color, c0.x, c0.y, tex_mode), i1 = tex_u8(frame_color, c1.x, c1.y, tex_mode), i2 = tex_u8(frame_color, c2.x, c2.y, tex_mode);
-        t->r1 = (180.f * (i1 - i0)) - d1;
-        t->r2 = (180.f * (i2 - i0)) - d2;
+        if (!BSO_LITERAL) {
+          const float b0 = tex_u8_b(frame_color, c0.x, c0.y, tex_mode), b1 = tex_u8_b(frame_color, c1.x, c1.y, tex_mode), b2 = tex_u8_b(frame_color, c2.x, c2.y, tex_mode);
+          t->r1 = BSO_FMA(BSO_DESC_SCALE, b1 - b0, -d1);
+          t->r2 = BSO_FMA(BSO_DESC_SCALE, b2 - b0, -d2);
+        } else {
+          const float i0 = tex_u8(frame_color, c0.x, c0.y, tex_mode), i1 = tex_u8(frame_color, c1.x, c1.y, tex_mode), i2 = tex_u8(frame_color, c2.x, c2.y, tex_mode);
+          t->r1 = (180.f * (i1 - i0)) - d1;
+          t->r2 = (180.f * (i2 - i0)) - d2;
+        }
         if (need_jacobians) {
           float cdx, cdy, t1dx, t1dy, t2dx, t2dy;
           point_gradient_u8(frame_color, c0, &cdx, &cdy);
           point_gradient_u8(frame_color, c1, &t1dx, &t1dy);
           point_gradient_u8(frame_color, c2, &t2dx, &t2dy);
-          float gx1 = 180.f * (t1dx - cdx), gy1 = 180.f * (t1dy - cdy), gx2 = 180.f * (t2dx - cdx), gy2 = 180.f * (t2dy - cdy);
+          const float scale = BSO_LITERAL ? 180.f : BSO_DESC_SCALE;   /* the twin's gradients are in byte units */
+          float gx1 = scale * (t1dx - cdx), gy1 = scale * (t1dy - cdy), gx2 = scale * (t2dx - cdx), gy2 = scale * (t2dy - cdy);
           gx1 *= color_camera->fx; gx2 *= color_camera->fx;
           gy1 *= color_camera->fy; gy2 *= color_camera->fy;
           bso_jac_desc_pose(gx1, gy1, local, t->J1);

@@ -48,3 +48,30 @@ def test_device_and_oracle_probes_agree(oracle):
         a, b = hip(kind, x).astype(np.float64), oracle_probe(kind, x).astype(np.float64)
         scale = np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-30)
         assert (np.abs(a - b) / scale).max() < 2e-6, (name, (np.abs(a - b) / scale).max())
+
+
+def test_midrange_reciprocal_is_correctly_rounded():
+    """rcp_rn_midrange (csrc/device_math.hpp: v_rcp + the fma chain of the compiler's own IEEE-division expansion, 7 instructions
+    instead of 11) feeds the association predicates, whose integer outputs are compared bit for bit with the CPU: it must equal
+    1.0f / x exactly.  Swept over EVERY fp32 mantissa at three exponents (the rounding of a reciprocal does not depend on the
+    exponent inside the normal range) and 4 M random finite values in 2^-90 .. 2^90, both signs."""
+    ctx = badslam_amd.Context(0)
+    L = badslam_amd.lib()
+
+    def run(x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros((x.size, 2), np.float32)
+        badslam_amd.check(L.bslam_debug_jacobians(ctx.handle, None, 7, x.size, x.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    for exp in (127, 100, 140):
+        x = (mant | np.uint32(exp << 23)).view(np.float32)
+        out = run(x)
+        assert np.array_equal(out[:, 0].view(np.uint32), out[:, 1].view(np.uint32)), exp
+        assert np.array_equal(out[:, 1], (np.float32(1) / x).astype(np.float32))          # and both equal the IEEE quotient
+    rng = np.random.default_rng(3)
+    bits = (rng.integers(37, 217, 1 << 22, dtype=np.uint32) << 23) | rng.integers(0, 1 << 23, 1 << 22, dtype=np.uint32) | (rng.integers(0, 2, 1 << 22, dtype=np.uint32) << 31)
+    out = run(bits.view(np.float32))
+    assert np.array_equal(out[:, 0].view(np.uint32), out[:, 1].view(np.uint32))

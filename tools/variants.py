@@ -35,12 +35,14 @@ def build(specs):
 def bench(args):
     for so in sorted(glob.glob(os.path.join(OUT, "*.so"))):
         env = dict(os.environ, BSLAM_HIP_LIB=so)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline", "0"] + args, env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline", "0", "--pcg", "0", "--secondary", "0"] + args, env=env,
+                           capture_output=True, text=True)
         name = os.path.basename(so)[len("libbadslam_hip_"):-3]
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
             roof = j["roofline"]
-            print(f"{name:24s} ms/step {j['ms_per_step']:9.3f}  pose_acc {roof['avg_launch_us']:8.1f} us  geometry {roof['geometry_kernel']['avg_launch_us']:8.1f} us", flush=True)
+            print(f"{name:24s} ms/step {j['ms_per_step']:9.3f}  pose_acc {roof['avg_launch_us']:9.1f} us (frac {roof['frac']:.3f})  geometry {roof['geometry_kernel']['us_per_step']:9.1f} us/step "
+                  f"(frac {roof['geometry_kernel']['frac']:.3f})", flush=True)
         except Exception:
             print(name, "FAILED", r.stdout[-500:], r.stderr[-1500:], flush=True)
 
