@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -306,11 +307,13 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   const SurfelRows rows = surfel_rows(surfels, surfels_size);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   float* partials = (float*)ctx->partials.ptr;
+  // tuning aid: BSLAM_DEBUG_POSE_LDS = bytes of (unused) dynamic LDS per block, to cap the blocks per CU without touching the code
+  static const unsigned debug_lds = getenv("BSLAM_DEBUG_POSE_LDS") ? (unsigned)atoi(getenv("BSLAM_DEBUG_POSE_LDS")) : 0u;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), 0, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   }
   BSLAM_HIP_TRY(hipGetLastError());
   if (!reduce_rows) return BSLAM_OK;   // the caller's pose_reduce_solve_kernel sums the rows itself

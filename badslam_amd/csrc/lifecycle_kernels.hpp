@@ -322,6 +322,20 @@ __device__ __forceinline__ float tex_channel_direct(const CamConsts& c, const Kf
   return tex_filter(q, f.a, f.b);
 }
 
+// the luma channel in byte units through the residual path's filter (device_math.hpp: bilinear_bytes): the initial descriptor
+// is ComputeRawDescriptorResidual with a zero descriptor (:141-152), i.e. the same arithmetic as every later residual
+__device__ __forceinline__ float tex_luma_bytes_direct(const CamConsts& c, const KfImages& kf, float x, float y) {
+  const TexFootprint f = tex_footprint(c, x, y);
+  auto texel = [&](int ix, int iy) {
+    ix = max(0, min(ix, c.color_width - 1));
+    iy = max(0, min(iy, c.color_height - 1));
+    return (float)gload(kf.color + (size_t)iy * kf.color_pitch + 4 * (size_t)ix + 3);
+  };
+  LumaQuad q;
+  q.tl = texel(f.i, f.j); q.tr = texel(f.i + 1, f.j); q.bl = texel(f.i, f.j + 1); q.br = texel(f.i + 1, f.j + 1);
+  return bilinear_bytes(q, f.a, f.b);
+}
+
 // CreateSurfelsForKeyframeCUDACreationAppendKernel + CreateNewSurfel (:96-161, 357-385)
 __global__ __launch_bounds__(256) void create_append_kernel(CamConsts c, KfImages kf, M34 global_T_frame, const uint8_t* __restrict__ flags,
                                                            const uint32_t* __restrict__ indices, uint32_t surfels_size, SurfelRowsAll s) {
@@ -344,11 +358,11 @@ __global__ __launch_bounds__(256) void create_append_kernel(CamConsts c, KfImage
   s.color[si] = col;
   f2 t1, t2;
   tangent_projections(gp, gn, radius_squared, kf.frame_T_global, c, &t1, &t2);   // the unquantised normal, as in the reference (:124-131)
-  const float intensity = tex_channel_direct(c, kf, color_pxy.x, color_pxy.y, 3);
-  const float i1 = tex_channel_direct(c, kf, t1.x, t1.y, 3);
-  const float i2 = tex_channel_direct(c, kf, t2.x, t2.y, 3);
-  s.d1[si] = (180.f * (i1 - intensity)) - 0.f;
-  s.d2[si] = (180.f * (i2 - intensity)) - 0.f;
+  const float b0 = tex_luma_bytes_direct(c, kf, color_pxy.x, color_pxy.y);
+  const float b1 = tex_luma_bytes_direct(c, kf, t1.x, t1.y);
+  const float b2 = tex_luma_bytes_direct(c, kf, t2.x, t2.y);
+  s.d1[si] = __builtin_fmaf(kDescScale, b1 - b0, -0.f);
+  s.d2[si] = __builtin_fmaf(kDescScale, b2 - b0, -0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
