@@ -453,6 +453,12 @@ int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_laun
   return BSLAM_OK;
 }
 
+int bslam_set_geometry_descriptor_legacy(bslam_context* ctx, int enable) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->geom_desc_legacy = enable != 0;
+  return BSLAM_OK;
+}
+
 int bslam_assign_colors(
     bslam_context* ctx, void* stream_, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
     const bslam_depth_params* depth_params, int keyframe_count, const bslam_keyframe_view* keyframes, uint32_t surfels_size,
@@ -801,7 +807,10 @@ int bslam_optimize_geometry_iteration(
 #define BSLAM_GEOM_R 3
 #endif
   Schedule sc;
-  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? 1 : BSLAM_GEOM_R, &sc))) return rc;
+#ifndef BSLAM_GEOM_R_DESC
+#define BSLAM_GEOM_R_DESC 2
+#endif
+  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? (ctx->geom_desc_legacy ? 1 : BSLAM_GEOM_R_DESC) : BSLAM_GEOM_R, &sc))) return rc;
   const dim3 grid(8u * sc.slots_per_xcd), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
@@ -838,8 +847,37 @@ int bslam_optimize_geometry_iteration(
       }
     }
   }
-  else if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
-  else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  else if (ctx->geom_desc_legacy) {   // one surfel per thread, one launch over the whole keyframe list (A/B measurements)
+    if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+    else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
+  } else {
+    // photometric iteration: BSLAM_GEOM_R_DESC surfels per thread, at most one resident grid per launch, keyframe chunks with the
+    // per-surfel sums carried in scratch (4 floats for the normals pass, 8 for the joint position + descriptor pass)
+#ifndef BSLAM_GEOM_WG_PER_CU_DESC
+#define BSLAM_GEOM_WG_PER_CU_DESC 4
+#endif
+    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU_DESC) / 8u);   // slots per XCD and launch
+    const int kf_chunk = ctx->geom_kf_chunk > 0 ? ctx->geom_kf_chunk : keyframe_count;
+    float* acc = nullptr;
+    uint32_t acc_pitch = 0;
+    if (keyframe_count > kf_chunk) {
+      acc_pitch = (surfels_size + 63u) & ~63u;
+      if ((rc = ctx->exchange.reserve((size_t)acc_pitch * 8 * sizeof(float)))) return rc;
+      acc = (float*)ctx->exchange.ptr;
+    }
+    for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
+      const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int k0 = 0; k0 < keyframe_count; k0 += kf_chunk) {
+          const int k1 = std::min(keyframe_count, k0 + kf_chunk);
+          const int fc = k0 == 0, lc = k1 == keyframe_count;
+          if (pass == 0) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 0, true>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
+          else if (use_depth_residuals) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, true>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
+          else hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, false>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
+        }
+      }
+    }
+  }
   }
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;

@@ -543,4 +543,127 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
   }
 }
 
+// The joint position + descriptor iteration (kMode 2 of geometry_kernel) in the same launch shape as geometry_chunk_kernel: R surfels
+// per thread walked keyframe by keyframe, one resident grid per launch, the keyframe list cut into chunks whose per-surfel sums
+// travel in library scratch (acc: 4 floats per surfel for the normals pass, 8 for the joint pass).  Sums are formed in keyframe
+// order: same bits as geometry_kernel<2, kDepth>.  kPass 0: normals (= geometry_chunk_kernel's pass 0, repeated here so that a
+// photometric iteration needs no geometry-only instantiation of a different R); kPass 1: position + descriptors
+// (BS/kernel_opt_geometry.cu:118-231, 273-361).
+#ifndef BSLAM_GEOM_DESC_WAVES
+#define BSLAM_GEOM_DESC_WAVES 4
+#endif
+template <int R, int kPass, bool kDepth>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_DESC_WAVES))) void geometry_desc_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
+                                                                 Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x + (first_i << 3), &slot)) return;
+  constexpr int kAcc = kPass == 0 ? 4 : 8;
+  uint32_t idx[R];
+  bool on[R];
+  f3 gp[R], gn[R], tp1[R], tp2[R];
+  float desc1[R], desc2[R];
+  float a[R][kAcc];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    idx[r] = surfel_of_slot(sc, slot, r, R);
+    on[r] = idx[r] < s.size;
+    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    const uint32_t j = on[r] ? idx[r] : 0;
+    gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
+    gn[r] = unpack_normal(s.normal[j]);
+    if (kPass == 1) {
+      desc1[r] = s.d1[j]; desc2[r] = s.d2[j];
+      tangent_points(gp[r], gn[r], s.radius_squared[j], &tp1[r], &tp2[r]);
+    }
+#pragma unroll
+    for (int q = 0; q < kAcc; ++q) a[r][q] = (!first_chunk && on[r]) ? acc[(size_t)q * acc_pitch + j] : 0.f;
+  }
+  for (int k = k_begin; k < k_end; ++k) {
+    const KfDev kf = kfs[k];
+    if (kf.activation == BSLAM_KF_INACTIVE) continue;
+    const float* Rm = kf.global_R_frame;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      Proj p;
+      if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      if (kPass == 0) {
+        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        a[r][0] += rot_row(Rm[0], Rm[1], Rm[2], ln);
+        a[r][1] += rot_row(Rm[3], Rm[4], Rm[5], ln);
+        a[r][2] += rot_row(Rm[6], Rm[7], Rm[8], ln);
+        a[r][3] += 1.f;
+      } else {
+        // accumulators: [0] H00, [1] H01, [2] H02, [3] H11, [4] H22, [5] b0, [6] b1, [7] b2   (H12 is never accumulated: quirk Q2)
+        const f3 rn = p.n_local;
+        if (kDepth) {
+          const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
+          const float dj = depth_position_jacobian(inv_stddev);
+          const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
+          const float raw = depth_residual(inv_stddev, rn, lu, p.local);
+          const float w = depth_weight(raw);
+          a[r][0] += w * dj * dj;
+          a[r][5] += w * raw * dj;
+        }
+        f2 color_pxy;
+        if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
+          f2 t1, t2;
+          project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+          float r1, rr2, gx1, gy1, gx2, gy2;
+          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+          const float jp1 = descriptor_position_jacobian(gx1, gy1, c.cfx, c.cfy, rn, p.local);
+          const float jp2 = descriptor_position_jacobian(gx2, gy2, c.cfx, c.cfy, rn, p.local);
+          const float jd = -1.f;
+          const float w1 = desc_weight(r1);
+          const float wr1 = w1 * r1;
+          const float w2 = desc_weight(rr2);
+          const float wr2 = w2 * rr2;
+          a[r][0] += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+          a[r][1] += w1 * jp1 * jd;
+          a[r][3] += w1 * jd * jd;
+          a[r][5] += wr1 * jp1 + wr2 * jp2;
+          a[r][6] += wr1 * jd;
+          a[r][2] += w2 * jp2 * jd;
+          a[r][4] += w2 * jd * jd;
+          a[r][7] += wr2 * jd;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!on[r]) continue;
+    const uint32_t j = idx[r];
+    if (!last_chunk) {
+#pragma unroll
+      for (int q = 0; q < kAcc; ++q) acc[(size_t)q * acc_pitch + j] = a[r][q];
+    } else if (kPass == 0) {
+      if (a[r][3] >= 1) {
+        const float inv = 1.f / a[r][3];
+        s.normal[j] = pack_normal(mk3(inv * a[r][0], inv * a[r][1], inv * a[r][2]));
+      }
+    } else {
+      float H00 = a[r][0], H01 = a[r][1], H02 = a[r][2], H11 = a[r][3], H12 = 0.f, H22 = a[r][4];
+      H00 += 1e-6f; H11 += 1e-6f; H22 += 1e-6f;
+      H00 = sqrtf(H00);
+      H01 = H01 / H00;
+      H11 = sqrtf(H11 - H01 * H01);
+      H02 = H02 / H00;
+      H12 = (H12 - H02 * H01) / H11;
+      H22 = sqrtf(H22 - H02 * H02 - H12 * H12);
+      const float y0 = a[r][5] / H00;
+      const float y1 = (a[r][6] - H01 * y0) / H11;
+      const float y2 = (a[r][7] - H02 * y0 - H12 * y1) / H22;
+      const float x2 = y2 / H22;
+      const float x1 = (y1 - H12 * x2) / H11;
+      const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
+      if (x0 != 0) {
+        const f3 np = sub3(gp[r], scale3(x0, gn[r]));
+        s.x[j] = np.x; s.y[j] = np.y; s.z[j] = np.z;
+      }
+      if (x1 != 0) s.d1[j] = fmaxf(-180.f, fminf(180.f, desc1[r] - x1));
+      if (x2 != 0) s.d2[j] = fmaxf(-180.f, fminf(180.f, desc2[r] - x2));
+    }
+  }
+}
+
 }  // namespace bslam

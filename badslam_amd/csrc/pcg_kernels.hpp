@@ -356,8 +356,11 @@ __global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(
 // ---------------------------------------------------------------------------------------------
 // PCGStep1 for all keyframes (BS/kernel_pcg.cu:645-1025)
 // ---------------------------------------------------------------------------------------------
+#ifndef BSLAM_PCG_STEP1_WAVES_DESC
+#define BSLAM_PCG_STEP1_WAVES_DESC 3
+#endif
 template <bool kDepth, bool kDesc, bool kIntr>
-__global__ __launch_bounds__(kPcgThreads) void pcg_step1_kernel(
+__global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_PCG_STEP1_WAVES_DESC : 4))) void pcg_step1_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
   uint32_t slot;

@@ -318,6 +318,9 @@ int bslam_debug_association(
  * at most `keyframes_per_launch` keyframes, with the per-surfel sums carried in library scratch (results are bit-identical
  * to a single launch).  Default 128; 0 = always one launch. */
 int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch);
+/* 1: the photometric geometry iteration runs as ONE launch of the one-surfel-per-thread kernel over the whole keyframe list
+ * (the round-1 form; bit-identical results, kept for A/B measurements and as the parity reference of the chunked form). */
+int bslam_set_geometry_descriptor_legacy(bslam_context* ctx, int enable);
 
 /* Replaces AssignColorsCUDA (BS/kernels.h:301-308, BS/kernel_assign_colors.cc:40-80, .cu:42-125): every surfel's
  * colour row becomes the mean of the bilinearly filtered uchar4 colours of the pixels it is associated with over ALL

@@ -457,3 +457,36 @@ def test_many_small_keyframes(oracle):
     scene.optimize_geometry_iteration()
     assert np.array_equal(chunked[3].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
     assert np.abs(chunked[:3] - scene.surfels[:3, :n]).max() < 1e-5
+
+
+def test_photometric_geometry_chunked_equals_single_launch(oracle):
+    """The photometric (position + descriptor) geometry iteration in its production shape -- several surfels per thread, resident grids,
+    keyframe chunks with the per-surfel sums carried in scratch -- is bit-identical to the one-launch one-surfel-per-thread kernel,
+    for a chunk size that divides the keyframe list unevenly, for the whole list in one chunk, and agrees with the oracle."""
+    from tests import gpu_util
+    cam = bso.make_camera(131.25, 131.25, 80.0, 60.0, 160, 120)
+    scene = scenes.synthetic_scene(37, seed=17, width=160, height=120, camera=cam, use_depth_residuals=True, use_descriptor_residuals=True)
+    hip = gpu_util.Hip(scene.to_device("cuda:0"))
+    n = scene.surfels_size
+    scene.update_activation()
+    hip.update_activation()
+    start = hip.d.surfels.clone()
+    L, h = hip.L, hip.ctx.handle
+    results = {}
+    for name, legacy, chunk in (("legacy", 1, 0), ("chunk16", 0, 16), ("chunk5", 0, 5), ("one chunk", 0, 0)):
+        hip.d.surfels.copy_(start)
+        badslam_amd.check(L.bslam_set_geometry_descriptor_legacy(h, legacy))
+        badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, chunk))
+        hip.optimize_geometry_iteration()
+        results[name] = hip.d.surfels_np()[:8, :n].copy()
+    badslam_amd.check(L.bslam_set_geometry_descriptor_legacy(h, 0))
+    badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, 128))
+    for name in ("chunk16", "chunk5", "one chunk"):
+        assert np.array_equal(results[name].view(np.uint32), results["legacy"].view(np.uint32)), name
+    moved = np.abs(results["legacy"][:3] - start.cpu().numpy()[:3, :n]).max()
+    assert moved > 1e-5                                              # the iteration did something
+    scene.optimize_geometry_iteration()
+    got = results["chunk16"]
+    assert np.array_equal(got[3].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
+    assert np.abs(got[:3] - scene.surfels[:3, :n]).max() < 1e-5
+    assert np.abs(got[6:8] - scene.surfels[6:8, :n]).max() < 2e-3    # descriptors (range +-180)
