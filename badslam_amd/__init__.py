@@ -54,6 +54,13 @@ def check(rc):
         raise BadSlamError(f"bslam error {rc}: {lib().bslam_last_error().decode()}")
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (bslam_comm_get_unique_id): rank 0 creates it, every rank passes it to Context.comm_init."""
+    buf = C.create_string_buffer(128)
+    check(lib().bslam_comm_get_unique_id(buf, 128))
+    return buf.raw
+
+
 class Context:
     """RAII wrapper of bslam_context."""
 
@@ -67,6 +74,14 @@ class Context:
 
     def set_texture_mode(self, mode):
         check(lib().bslam_set_texture_mode(self._ctx, mode))
+
+    def comm_init(self, unique_id, rank, world_size):
+        """The library's own RCCL communicator for surfel-sharded runs (bslam_comm_init)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib().bslam_comm_init(self._ctx, buf, rank, world_size))
+
+    def comm_destroy(self):
+        check(lib().bslam_comm_destroy(self._ctx))
 
     def close(self):
         if self._ctx:

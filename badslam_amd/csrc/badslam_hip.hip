@@ -1,6 +1,7 @@
 // badslam_hip.hip -- C ABI entry points (include/badslam_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -327,6 +328,53 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
 
 }  // namespace bslam
 
+// ---- native exchange: an RCCL communicator owned by the context ------------------------------------------------------
+// librccl is opened at run time (dlopen) the first time a communicator is asked for: the kernel library itself has no link
+// dependency on it, a single-GPU user never loads it, and a process that already holds an RCCL (e.g. the one PyTorch ships)
+// shares that copy -- dlopen by soname returns the loaded library.
+namespace {
+using bslam::fail;
+struct RcclId128 { char b[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int load_rccl() {
+  if (g_rccl.handle) return BSLAM_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+  if (!h) return fail(BSLAM_ERR_HIP, "RCCL not found (dlopen librccl.so.1: %s)", dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+    dlclose(h);
+    return fail(BSLAM_ERR_HIP, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+  }
+  g_rccl.handle = h;
+  return BSLAM_OK;
+}
+const char* rccl_error(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?"; }
+}  // namespace
+
+namespace bslam {
+int rccl_allreduce_sum(bslam_context* ctx, hipStream_t stream, float* device_buffer, size_t count) {
+  if (count == 0) return BSLAM_OK;
+  // ncclFloat32 = 7, ncclSum = 0 (rccl.h); in place, on the caller's stream: ordered after the producers the library enqueued
+  const int e = g_rccl.AllReduce(device_buffer, device_buffer, count, 7, 0, ctx->comm, stream);
+  if (e != 0) return fail(BSLAM_ERR_HIP, "ncclAllReduce(%zu floats) failed: %s", count, rccl_error(e));
+  return BSLAM_OK;
+}
+}  // namespace bslam
+
 using namespace bslam;
 
 extern "C" {
@@ -356,6 +404,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
 int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
+  bslam_comm_destroy(ctx);
   ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
@@ -376,6 +425,45 @@ int bslam_set_allreduce(bslam_context* ctx, bslam_allreduce_fn allreduce, void* 
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->allreduce = allreduce;
   ctx->allreduce_user = allreduce_user;
+  return BSLAM_OK;
+}
+
+int bslam_comm_get_unique_id(void* out_id, size_t bytes) {
+  if (!out_id || bytes < BSLAM_COMM_UNIQUE_ID_BYTES) return fail(BSLAM_ERR_INVALID_ARGUMENT, "need a buffer of %d bytes", BSLAM_COMM_UNIQUE_ID_BYTES);
+  int rc = load_rccl();
+  if (rc) return rc;
+  const int e = g_rccl.GetUniqueId(out_id);
+  if (e != 0) return fail(BSLAM_ERR_HIP, "ncclGetUniqueId failed: %s", rccl_error(e));
+  return BSLAM_OK;
+}
+
+int bslam_comm_init(bslam_context* ctx, const void* unique_id, int rank, int world_size) {
+  if (!ctx || !unique_id) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(BSLAM_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world_size);
+  if (ctx->comm) return fail(BSLAM_ERR_INVALID_ARGUMENT, "the context already has a communicator (bslam_comm_destroy first)");
+  int rc = load_rccl();
+  if (rc) return rc;
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  RcclId128 id;
+  std::memcpy(id.b, unique_id, sizeof(id.b));
+  void* comm = nullptr;
+  const int e = g_rccl.CommInitRank(&comm, world_size, id, rank);
+  if (e != 0) return fail(BSLAM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world_size, rccl_error(e));
+  ctx->comm = comm;
+  ctx->comm_rank = rank;
+  ctx->comm_world = world_size;
+  return BSLAM_OK;
+}
+
+int bslam_comm_destroy(bslam_context* ctx) {
+  if (!ctx) return BSLAM_OK;
+  if (ctx->comm) {
+    hipError_t he = hipSetDevice(ctx->device); (void)he;
+    const int e = g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1; ctx->comm_rank = 0;
+    if (e != 0) return fail(BSLAM_ERR_HIP, "ncclCommDestroy failed: %s", rccl_error(e));
+  }
   return BSLAM_OK;
 }
 
@@ -668,7 +756,8 @@ int bslam_estimate_frame_poses_batched(
   // unconverged on its way to h_active[it % 4].
   auto enqueue_iteration = [&](int it) -> int {
     const int slot = it & 3;
-    const bool fused = surfels_size > 0 && !allreduce;
+    const bool exchange = allreduce != nullptr || has_exchange(ctx);   // the call's own hook, else the context's hook / RCCL communicator
+    const bool fused = surfels_size > 0 && !exchange;
     // Later slots are zeroed by the previous iteration's solve kernel.
     if (it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
     if (fused) {
@@ -692,6 +781,9 @@ int bslam_estimate_frame_poses_batched(
         // rows of converged keyframes are zeros on every rank; the solve kernel ignores them.
         const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
         if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
+      } else if (exchange) {
+        const int arc = exchange_sum(ctx, stream, (float*)ctx->coeffs.ptr, (size_t)keyframe_count * kRow);
+        if (arc) return arc;
       }
       hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
                          (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));

@@ -138,6 +138,8 @@ struct bslam_context {
   bslam::Slab exchange;      // staging of the multi-rank exchanges (PCG shared unknowns, intrinsics sums)
   bslam_allreduce_fn allreduce = nullptr;   // bslam_set_allreduce: sum across the ranks of a surfel-sharded run
   void* allreduce_user = nullptr;
+  void* comm = nullptr;                     // bslam_comm_init: RCCL communicator (ncclComm_t) of the surfel-sharded run
+  int comm_rank = 0, comm_world = 1;
   bslam::Slab order;
   bool use_schedule = true;
   const void* order_key_ptr = nullptr;
@@ -156,6 +158,20 @@ struct bslam_context {
 };
 
 namespace bslam {
+// The exchange of a surfel-sharded run: an in-place float sum across ranks, ordered on `stream`.  A caller-supplied hook
+// (bslam_set_allreduce) takes precedence over the library's own RCCL communicator (bslam_comm_init).
+int rccl_allreduce_sum(bslam_context* ctx, hipStream_t stream, float* device_buffer, size_t count);   // badslam_hip.hip
+inline bool has_exchange(const bslam_context* ctx) { return ctx->allreduce != nullptr || ctx->comm != nullptr; }
+inline int exchange_sum(bslam_context* ctx, hipStream_t stream, float* device_buffer, size_t count) {
+  if (ctx->allreduce) {
+    const int arc = ctx->allreduce(ctx->allreduce_user, device_buffer, count, stream);
+    if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
+    return BSLAM_OK;
+  }
+  if (ctx->comm) return rccl_allreduce_sum(ctx, stream, device_buffer, count);
+  return BSLAM_OK;
+}
+
 // Brackets one kernel launch with events when profiling is on.
 struct ProfScope {
   bslam_context* ctx; hipStream_t stream; std::pair<hipEvent_t, hipEvent_t> ev; bool on; int tag;

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     const uint32_t j = on[r] ? idx[r] : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
-    if (kPass == 1) {
+    if constexpr (kPass == 1) {
       desc1[r] = s.d1[j]; desc2[r] = s.d2[j];
       tangent_points(gp[r], gn[r], s.radius_squared[j], &tp1[r], &tp2[r]);
     }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     for (int r = 0; r < R; ++r) {
       Proj p;
       if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
-      if (kPass == 0) {
+      if constexpr (kPass == 0) {
         const f3 ln = u16_to_image_space_normal(p.pixel_normal);
         a[r][0] += rot_row(Rm[0], Rm[1], Rm[2], ln);
         a[r][1] += rot_row(Rm[3], Rm[4], Rm[5], ln);
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     if (!last_chunk) {
 #pragma unroll
       for (int q = 0; q < kAcc; ++q) acc[(size_t)q * acc_pitch + j] = a[r][q];
-    } else if (kPass == 0) {
+    } else if constexpr (kPass == 0) {
       if (a[r][3] >= 1) {
         const float inv = 1.f / a[r][3];
         s.normal[j] = pack_normal(mk3(inv * a[r][0], inv * a[r][1], inv * a[r][2]));

@@ -59,6 +59,8 @@ def host_lib():
     L.bsh_export_point_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, f32p, u8p, f32p, C.POINTER(C.c_uint64)]
     L.bsh_create_surfels_for_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.bsh_set_allreduce.argtypes = [C.c_void_p, abi.ALLREDUCE_FN, C.c_void_p]
+    L.bsh_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.bsh_comm_destroy.argtypes = [C.c_void_p]
     L.bsh_estimate_frame_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p]
     L.bsh_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bsh_get_intrinsics.argtypes = [C.c_void_p, f32p, f32p, f32p]
@@ -373,6 +375,14 @@ class DirectBA:
 
     def set_allreduce(self, callback):
         self._check(self.L.bsh_set_allreduce(self._ba, callback, None))
+
+    def InitComm(self, unique_id, rank, world_size):
+        """RCCL communicator inside this DirectBA's kernel context (unique_id: the 128 bytes of badslam_amd.comm_unique_id() of rank 0)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.L.bsh_comm_init(self._ba, buf, rank, world_size))
+
+    def DestroyComm(self):
+        self._check(self.L.bsh_comm_destroy(self._ba))
 
     def EstimateFramePose(self, kf_id, global_T_frame_initial_estimate):
         out = np.zeros(7, np.float32)

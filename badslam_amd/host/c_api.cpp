@@ -174,6 +174,8 @@ int bsh_set_options(void* ba, int batched_pose_optimization, int pcg_gauge_keyfr
   });
 }
 int bsh_set_allreduce(void* ba, bslam_allreduce_fn fn, void* user) { BSH_TRY(static_cast<DirectBA*>(ba)->SetAllReduce(fn, user)); }
+int bsh_comm_init(void* ba, const void* unique_id, int rank, int world_size) { BSH_TRY(static_cast<DirectBA*>(ba)->InitComm(unique_id, rank, world_size)); }
+int bsh_comm_destroy(void* ba) { BSH_TRY(static_cast<DirectBA*>(ba)->DestroyComm()); }
 
 int bsh_estimate_frame_pose(void* ba_, void* stream, int keyframe_id, const float* init7, float* out7) {
   BSH_TRY({

@@ -251,6 +251,17 @@ void DirectBA::SetAllReduce(bslam_allreduce_fn fn, void* user) {
   Check(bslam_set_allreduce(ctx_, fn, user), "bslam_set_allreduce");
 }
 
+void DirectBA::InitComm(const void* unique_id, int rank, int world_size) {
+  Check(bslam_comm_init(ctx_, unique_id, rank, world_size), "bslam_comm_init");
+  sharded_ = world_size > 1 || sharded_;
+  comm_ = true;
+}
+
+void DirectBA::DestroyComm() {
+  Check(bslam_comm_destroy(ctx_), "bslam_comm_destroy");
+  comm_ = false;
+}
+
 void DirectBA::InvalidateKeyframeCache() { Check(bslam_invalidate_keyframe_cache(ctx_), "bslam_invalidate_keyframe_cache"); }
 
 void DirectBA::SetTextureMode(int mode) { Check(bslam_set_texture_mode(ctx_, mode), "bslam_set_texture_mode"); }
@@ -861,7 +872,12 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
     L.color_intrinsics_unknown_start_index = kInvalid;
     if (optimize_color_intrinsics) { L.color_intrinsics_unknown_start_index = cur; cur += 4u; }
     L.unknown_count = cur;
-    L.gauge_keyframe_id = fixed_gauge_keyframe_ >= 0 ? fixed_gauge_keyframe_ % K : std::rand() % K;   // :328
+    // :328 picks rand() % K.  In a surfel-sharded run every rank must pick the SAME gauge keyframe (the all-reduced r, M, g and
+    // the pose rows share one unknown layout), and rand() sequences are per process: there the choice is derived from the BA
+    // iteration counter, which all ranks advance in lock step.
+    const bool exchange = allreduce_ != nullptr || comm_;
+    L.gauge_keyframe_id = fixed_gauge_keyframe_ >= 0 ? fixed_gauge_keyframe_ % K
+                          : (exchange ? static_cast<int>(static_cast<unsigned>(ba_iteration_count_) % static_cast<unsigned>(K)) : std::rand() % K);
     L.optimize_poses = optimize_poses; L.optimize_geometry = optimize_geometry;
     L.optimize_depth_intrinsics = optimize_depth_intrinsics; L.optimize_color_intrinsics = optimize_color_intrinsics;
     L.use_depth_residuals = use_depth_residuals_; L.use_descriptor_residuals = use_descriptor_residuals_;

@@ -226,6 +226,11 @@ class DirectBA {
   // Surfel-sharded multi-GPU runs: `fn` sums device buffers across ranks (RCCL / torch.distributed); it is
   // used by the batched pose step and, through the context, by the PCG and intrinsics entry points.
   void SetAllReduce(bslam_allreduce_fn fn, void* user);
+  // The library's own exchange: an RCCL communicator in this DirectBA's kernel context (bslam_comm_init).  rank 0 obtains the
+  // 128-byte id with bslam_comm_get_unique_id and hands it to every rank; after InitComm every BA scheme of this object
+  // (alternating pose step, PCG, intrinsics) sums its shared quantities over the ranks on the BA stream -- no callback.
+  void InitComm(const void* unique_id, int rank, int world_size);
+  void DestroyComm();
 
   void Lock() const { ba_thread_mutex_.lock(); }
   void Unlock() const { ba_thread_mutex_.unlock(); }
@@ -306,6 +311,7 @@ class DirectBA {
   bool scheme_end_tasks_ = true;
   int fixed_gauge_keyframe_ = -1;
   std::ostream* timings_stream_ = nullptr;
+  bool comm_ = false, sharded_ = false;
   bslam_allreduce_fn allreduce_ = nullptr;
   void* allreduce_user_ = nullptr;
   // phase timing (BS/direct_ba.h:513-532)

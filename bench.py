@@ -130,7 +130,7 @@ def measure(env, K, use_desc, steps, warmup, stack=None):
     badslam_amd.check(L.bslam_profile_read_counters(ctx.handle, counters))
     badslam_amd.check(L.bslam_profile_enable(ctx.handle, 0))
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=env.control_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -180,7 +180,7 @@ def measure(env, K, use_desc, steps, warmup, stack=None):
                    "pairs_per_step": {"activation_visited": pairs_activation / steps, "geometry": pairs_geometry / steps, "pose": pairs_pose / steps},
                    "active_surfel_fraction": active_surfel_steps / (steps * S),
                    "in_bounds_pair_fraction": frac_inb, "associated_pair_fraction": frac_assoc,
-                   "parallelism": f"surfel-shard x{world}"},
+                   "parallelism": f"surfel-shard x{world}", "exchange": env.exchange},
         "roofline": roof,
     }
 
@@ -204,33 +204,43 @@ def main():
     env.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one rank per GPU.  (Rehearsal on a one-GPU box: BSLAM_BENCH_BACKEND=gloo lets several ranks share the card --
-    # RCCL itself needs one GPU per rank.)
-    backend = os.environ.get("BSLAM_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    # One rank per GPU.  Default exchange ("native"): the library's own RCCL communicator (bslam_comm_init) -- the K x 32
+    # coefficient rows are summed by ncclAllReduce on the BA stream, no callback; torch.distributed (gloo) only carries the
+    # 128-byte communicator id, the barriers and the max over ranks of the wall time.  BSLAM_BENCH_BACKEND=nccl | gloo selects the
+    # older callback path through torch.distributed.all_reduce instead (gloo: rehearsal of N ranks sharing one card).
+    backend = os.environ.get("BSLAM_BENCH_BACKEND", "native")
+    dev_index = local_rank if backend != "gloo" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     env.device = device = f"cuda:{dev_index}"
+    env.control_device = device if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     env.L = L = badslam_amd.lib()
     env.ctx = ctx = badslam_amd.Context(dev_index)
     L.bslam_set_keyframe_cache(ctx.handle, 1)   # the bench never rewrites a keyframe image in place
     if os.environ.get("BSLAM_GEOM_KF_CHUNK"):   # tuning runs only; the default is the library's
         badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(ctx.handle, int(os.environ["BSLAM_GEOM_KF_CHUNK"])))
-    hook = AllReduceHook(device=True) if world > 1 else None
-    env.cb = hook.callback if hook else C.cast(None, abi.ALLREDUCE_FN)
-    if world == 1 and os.environ.get("BSLAM_BENCH_SELF_RCCL"):
-        # rehearsal of the N > 1 exchange on one GPU: a one-rank RCCL group, for which the all-reduce is the identity
-        # but goes through the same torch.distributed / RCCL launch and stream hand-over (not a bench configuration)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+    hook = None
+    env.cb = C.cast(None, abi.ALLREDUCE_FN)
+    env.exchange = "none"
+    if world > 1 and backend == "native":
+        uid = [badslam_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+        env.exchange = "RCCL ncclAllReduce inside libbadslam_hip (bslam_comm_init), on the BA stream"
+    elif world > 1:
         hook = AllReduceHook(device=True)
         env.cb = hook.callback
+        env.exchange = f"torch.distributed.all_reduce callback ({backend})"
+    if world == 1 and os.environ.get("BSLAM_BENCH_SELF_RCCL"):
+        # rehearsal of the N > 1 exchange on one GPU: a one-rank communicator, for which the all-reduce is the identity but
+        # goes through the same kernel sequence and RCCL launch (not a bench configuration)
+        ctx.comm_init(badslam_amd.comm_unique_id(), 0, 1)
+        env.exchange = "RCCL, one-rank rehearsal"
     if world == 1 and os.environ.get("BSLAM_BENCH_NOOP_HOOK"):
         # rehearsal of the N > 1 kernel sequence on one GPU: the exchange is a no-op callback (not a bench configuration)
         noop = abi.ALLREDUCE_FN(lambda user, ptr, count, stream: 0)

@@ -513,6 +513,19 @@ int bslam_compute_cost_and_residual_count_from_images(
  * The reference is single-GPU; this replaces nothing in it. */
 int bslam_set_allreduce(bslam_context* ctx, bslam_allreduce_fn allreduce, void* allreduce_user);
 
+/* The library's own exchange: an RCCL communicator owned by the context (bslam_comm_{init,destroy}).  One
+ * process per GPU; rank 0 obtains a unique id and hands its 128 bytes to every rank over any channel the application has
+ * (MPI, a socket, torch.distributed, a file); every rank then calls bslam_comm_init.  From then on every exchange point listed
+ * above -- and the K x 32 Gauss-Newton rows of bslam_estimate_frame_poses_batched when no hook is passed to it -- is an in-place
+ * ncclAllReduce(sum, float) enqueued on the call's own stream, i.e. on the BA stream: no host callback, no other runtime in
+ * the loop (the C++ host class needs no Python to shard).  A hook set with bslam_set_allreduce takes precedence.  RCCL is
+ * opened with dlopen at the first of these calls; the library has no link dependency on it.  The reference is single-GPU;
+ * these replace nothing in it. */
+#define BSLAM_COMM_UNIQUE_ID_BYTES 128
+int bslam_comm_get_unique_id(void* out_id, size_t bytes);
+int bslam_comm_init(bslam_context* ctx, const void* unique_id, int rank, int world_size);
+int bslam_comm_destroy(bslam_context* ctx);
+
 /* ------------------------------------------------------------------------- */
 /* PCG (matrix-free Gauss-Newton step)                                        */
 /* ------------------------------------------------------------------------- */

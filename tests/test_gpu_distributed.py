@@ -139,13 +139,15 @@ def _ba_scene():
     return scene
 
 
-def _run_ba(scene, lo, hi, use_pcg, depth_intr, hook=None):
+def _run_ba(scene, lo, hi, use_pcg, depth_intr, hook=None, comm_id=None):
     from badslam_amd.direct_ba import DirectBA
     ba = DirectBA(max(1, hi - lo), scene.raw_to_float_depth, scene.baseline_fx, scene.cell, 0.8, 1, 1, 1,
                   scene.color_camera, scene.depth_camera, 0, scene.use_depth_residuals, scene.use_descriptor_residuals)
     ba.set_options(pcg_gauge_keyframe=0, texture_mode=scene.tex_mode, scheme_end_tasks=False)   # keep the shard's surfel set fixed
     if hook is not None:
         ba.set_allreduce(hook.callback)
+    if comm_id is not None:
+        ba.InitComm(comm_id, 0, 1)          # the library's own RCCL communicator (one rank on the one card)
     for kf in scene.keyframes:
         ba.AddKeyframe(kf.id, max(kf.min_depth, 1e-3), max(kf.max_depth, 1e-2), kf.depth, kf.normals, kf.radius, kf.color, kf.global_T_frame)
     ba.SetSurfels(np.ascontiguousarray(scene.surfels[:8, lo:hi]), hi - lo)
@@ -215,3 +217,64 @@ def test_two_ranks_sharded_bundle_adjustment(tmp_path, oracle, use_pcg, depth_in
         # two shards; its bar is the same 5 % of the ~3 mm update as the pose bar above)
         q_bar, max_bar = (3e-4, 1e-3) if (use_pcg and depth_intr) else (2e-5, 5e-4)
         assert np.quantile(dz, 0.999) < q_bar and dz.max() < max_bar, (rank, float(np.quantile(dz, 0.999)), float(dz.max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# The library's own exchange: bslam_comm_init (RCCL inside the C-ABI, no callback, no Python in the loop)
+# ------------------------------------------------------------------------------------------------
+def _native_worker(rank, world, out_dir):
+    """One rank on the one card (RCCL needs a GPU per rank).  For one rank the all-reduce is the identity, so the native path
+    must equal, bit for bit, the same kernel sequence with a do-nothing callback -- through the C-ABI pose entry and through
+    the C++ host class (alternating, PCG, PCG + depth intrinsics, alternating + depth intrinsics)."""
+    import torch
+    torch.cuda.set_device(0)
+    import badslam_amd
+    from badslam_amd import abi
+    from tests import bso, gpu_util
+    bso.build_oracle()
+    scene, init = _scene()
+    uid = badslam_amd.comm_unique_id()
+    assert len(uid) == 128
+    # --- C-ABI: batched pose estimation
+    hip_native = gpu_util.Hip(scene.to_device("cuda:0"))
+    hip_native.ctx.comm_init(uid, 0, 1)
+    poses, iters, conv = hip_native.estimate_poses_batched(init)          # no hook argument: the context's communicator
+    hip_noop = gpu_util.Hip(scene.to_device("cuda:0"))
+    noop = abi.ALLREDUCE_FN(lambda user, ptr, count, stream: 0)
+    poses2, iters2, _ = hip_noop.estimate_poses_batched(init, allreduce=noop)
+    hip_plain = gpu_util.Hip(scene.to_device("cuda:0"))
+    poses3, iters3, _ = hip_plain.estimate_poses_batched(init)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "native_poses.npy"), _pose_array(poses))
+    np.save(os.path.join(out_dir, "noop_poses.npy"), _pose_array(poses2))
+    np.save(os.path.join(out_dir, "plain_poses.npy"), _pose_array(poses3))
+    np.save(os.path.join(out_dir, "iters.npy"), np.array([iters, iters2, iters3]))
+    hip_native.ctx.comm_destroy()
+    # --- C++ host class: whole BA calls
+    ba_scene = _ba_scene()
+    n = ba_scene.surfels_size
+
+    class Native:        # _run_ba's hook protocol: .callback is installed with set_allreduce; here InitComm instead
+        callback = None
+
+    for tag, (use_pcg, depth_intr) in {"pcg": (True, False), "pcg_intr": (True, True), "alt_intr": (False, True)}.items():
+        a = _run_ba(ba_scene, 0, n, use_pcg, depth_intr, comm_id=badslam_amd.comm_unique_id())
+        b = _run_ba(ba_scene, 0, n, use_pcg, depth_intr, hook=type("H", (), {"callback": noop})())
+        for name, x, y in zip(("poses", "surfels", "intr"), a, b):
+            np.save(os.path.join(out_dir, f"{tag}_{name}_native.npy"), x)
+            np.save(os.path.join(out_dir, f"{tag}_{name}_noop.npy"), y)
+
+
+def test_native_rccl_communicator_single_rank(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    mp.spawn(_native_worker, args=(1, str(tmp_path)), nprocs=1, join=True)
+    native, noop, plain = (np.load(tmp_path / f"{k}_poses.npy") for k in ("native", "noop", "plain"))
+    assert np.isfinite(native).all()
+    assert np.array_equal(native.view(np.uint32), noop.view(np.uint32)), "RCCL sum over one rank must be the identity"
+    assert np.abs(native - plain).max() < 1e-6          # fused single-GPU kernels: same rows, count column split differently
+    it = np.load(tmp_path / "iters.npy")
+    assert np.array_equal(it[0], it[1]) and np.array_equal(it[0], it[2])
+    for tag in ("pcg", "pcg_intr", "alt_intr"):
+        for name in ("poses", "surfels", "intr"):
+            a, b = np.load(tmp_path / f"{tag}_{name}_native.npy"), np.load(tmp_path / f"{tag}_{name}_noop.npy")
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tag, name)
