@@ -229,3 +229,118 @@ class DeviceStack:
             v.activation = activation
             v.id = k
         return arr
+
+
+class GeneratedStackMeta:
+    """Host-side description of a stack whose images live only in HBM (TorchStack): cameras, scalars and poses."""
+
+    def __init__(self, K, width, height, cell, camera, raw_to_float_depth, baseline_fx, R, t):
+        self.K, self.width, self.height, self.cell = K, width, height, cell
+        self.camera, self.raw_to_float_depth, self.baseline_fx = camera, np.float32(raw_to_float_depth), float(baseline_fx)
+        self.R, self.t = R, t
+        self.surfels_size = 0
+        self.cfactor = np.zeros(((height - 1) // cell + 1, (width - 1) // cell + 1), np.float32)
+
+    pose = SyntheticStack.pose
+
+
+class TorchStack(DeviceStack):
+    """The same synthetic scene family as SyntheticStack (random planes, photo-consistent texture, poses T0 * exp(xi), cell-4
+    surfels without merging), rendered directly in HBM with torch ops: the 300- and 1000-keyframe stacks of BASELINE.json
+    configs[2] / configs[4] take seconds instead of minutes.  Not bit-identical to SyntheticStack (different random streams for
+    the surfel noise, float64 on the device); the -m gpu tests that use it are property tests and oracle comparisons on data
+    copied back from the device."""
+
+    def __init__(self, num_keyframes, device, width=640, height=480, cell=4, seed=0xBAD51A4, fx=525.0, fy=525.0, cx=320.0, cy=240.0,
+                 raw_to_float_depth=1.0 / 5000, baseline_fx=40.0, translation_range=0.25, rotation_range=0.12, plane_count=20,
+                 surfel_noise=0.002):
+        import torch
+        self.torch = torch
+        self.device = device
+        rng = np.random.default_rng(seed)
+        planes = []
+        for _ in range(plane_count):
+            n = rng.uniform(-1, 1, 3)
+            n[2] = -1.0
+            planes.append(n / np.linalg.norm(n))
+        Rs, ts = [], []
+        for _ in range(num_keyframes):
+            xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
+            R, t = se3_exp(xi)
+            Rs.append(R)
+            ts.append(t)
+        cam = abi.Camera4f(fx, fy, cx, cy, width, height)
+        self.stack = GeneratedStackMeta(num_keyframes, width, height, cell, cam, raw_to_float_depth, baseline_fx, Rs, ts)
+        f64 = dict(dtype=torch.float64, device=device)
+        P = torch.tensor(np.stack(planes), **f64)                                   # [planes, 3]
+        xs = (torch.arange(width, **f64) - (cx - 0.5)) / fx
+        ys = (torch.arange(height, **f64) - (cy - 0.5)) / fy
+        dyg, dxg = torch.meshgrid(ys, xs, indexing="ij")
+        dirs = torch.stack([dxg, dyg, torch.ones_like(dxg)], dim=-1)                # [h, w, 3]
+        K = num_keyframes
+        self.depth = torch.empty((K, height, width), dtype=torch.int16, device=device)
+        self.normals = torch.empty((K, height, width), dtype=torch.int16, device=device)
+        self.radius = torch.empty((K, height, width), dtype=torch.int16, device=device)
+        self.color = torch.empty((K, height, width, 4), dtype=torch.uint8, device=device)
+        cw, ch = (width - 1) // cell + 1, (height - 1) // cell + 1
+        yy = torch.clamp(torch.arange(ch, device=device) * cell + 1, max=height - 2)
+        xx = torch.clamp(torch.arange(cw, device=device) * cell + 1, max=width - 2)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed) & 0x7FFFFFFF)
+        surf = []
+
+        def s8(v):
+            return (v * 127.0 + torch.where(v > 0, 0.5, -0.5)).to(torch.float32).to(torch.int32).to(torch.int8)
+
+        def s10(v):
+            return (v * 511.0 + torch.where(v > 0, 0.5, -0.5)).to(torch.float32).to(torch.int32) & 0x3FF
+
+        for k in range(K):
+            R = torch.tensor(Rs[k], **f64)
+            t = torch.tensor(ts[k], **f64)
+            dg = dirs @ R.T
+            denom = dg @ P.T
+            num = -(2.5 + P @ t)
+            tt = num[None, None, :] / denom
+            tt = torch.where((denom < 0) & (tt > 0.3), tt, torch.full_like(tt, float("inf")))
+            best, which = tt.min(dim=2)
+            bestn = P[which]
+            valid = torch.isfinite(best) & (best < 6.0)
+            valid[0, :] = False; valid[-1, :] = False; valid[:, 0] = False; valid[:, -1] = False
+            d = torch.where(valid, best / float(raw_to_float_depth) + 0.5, torch.full_like(best, 65535.0)).to(torch.int64)
+            valid &= d < 32768
+            d = torch.where(valid, d, torch.full_like(d, 65535))
+            self.depth[k] = d.to(torch.int32).to(torch.int16)               # two's complement bit pattern of the u16 value
+            n_cam = (bestn @ R).to(torch.float32)
+            packed = (s8(n_cam[..., 0]).to(torch.int32) & 0xFF) | ((s8(n_cam[..., 1]).to(torch.int32) & 0xFF) << 8)
+            self.normals[k] = torch.where(valid, packed, torch.zeros_like(packed)).to(torch.int16)
+            z = d.to(torch.float32) * float(np.float32(raw_to_float_depth))
+            r2 = torch.where(valid, (z / float(fx)) ** 2, torch.zeros_like(z)).to(torch.float16)
+            self.radius[k] = r2.view(torch.int16)
+            pts = t[None, None, :] + dg * torch.where(valid, best, torch.zeros_like(best))[..., None]
+            lum = (torch.sin(7.0 * pts[..., 0] + 0.37) + torch.sin(9.0 * pts[..., 1] + 0.5) + torch.sin(11.0 * pts[..., 2] + 0.7)
+                   + 0.5 * torch.sin(23.0 * (pts[..., 0] + pts[..., 1])) + 0.5 * torch.cos(17.0 * (pts[..., 1] - pts[..., 2])))
+            lum = torch.clamp((lum + 4.0) / 8.0 * 255.0, 0, 255).to(torch.uint8)
+            self.color[k] = lum[..., None].expand(-1, -1, 4)
+            v = valid[yy][:, xx]
+            zc = z[yy][:, xx][v]
+            pcam = torch.stack([zc * dxg[yy][:, xx][v].to(torch.float32), zc * dyg[yy][:, xx][v].to(torch.float32), zc], dim=-1).to(torch.float64)
+            bn = bestn[yy][:, xx][v]
+            pg = pcam @ R.T + t[None, :]
+            pg = pg + bn * ((torch.rand((pg.shape[0], 1), generator=gen, **f64) * 2 - 1) * surfel_noise)
+            s = torch.zeros((abi.SURFEL_ATTRIBUTE_COUNT, pg.shape[0]), dtype=torch.float32, device=device)
+            s[0:3] = pg.T.to(torch.float32)
+            bnf = bn.to(torch.float32)
+            s[3] = (s10(bnf[:, 0]) | (s10(bnf[:, 1]) << 10) | (s10(bnf[:, 2]) << 20)).view(torch.float32)
+            s[4] = r2[yy][:, xx][v].to(torch.float32)
+            surf.append(s)
+        self.surfels = torch.cat(surf, dim=1).contiguous()
+        self.surfels_size = self.surfels.shape[1]
+        self.stack.surfels_size = self.surfels_size
+        self.active = torch.ones((1, max(1, self.surfels_size)), dtype=torch.uint8, device=device)
+        self.cfactor = torch.zeros(self.stack.cfactor.shape, dtype=torch.float32, device=device)
+
+    def host_keyframe(self, k):
+        """(depth u16, normals u16, radius u16, color uchar4) of keyframe k copied back to host arrays (oracle comparisons)."""
+        g = lambda t: np.ascontiguousarray(t[k].cpu().numpy())
+        return g(self.depth).view(np.uint16), g(self.normals).view(np.uint16), g(self.radius).view(np.uint16), g(self.color)

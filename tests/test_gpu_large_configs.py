@@ -1,0 +1,132 @@
+"""-m gpu: the two BASELINE.json configurations no other test reaches at full size, on ONE GPU:
+
+  configs[2]  ~300 keyframes, full photometric + geometric BA, 5.76 M surfels  (TUM fr3/long_office shape)
+  configs[4]  1000 keyframes x 19.2 M surfels, geometry only                   (the 8-GPU synthetic workload, whole on one card)
+
+The oracle would need hours here, so the checks are the size-independent properties of the domain -- determinism, additivity of
+the Gauss-Newton coefficients over surfel shards (what the multi-GPU partition relies on), idempotence of the activation pass,
+bit-identical chunked vs unchunked geometry -- plus, at configs[2], an oracle comparison of a few keyframes' H / b on the data
+copied back from the device.  Stacks are rendered in HBM (badslam_amd.synthetic.TorchStack)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import badslam_amd
+from badslam_amd import abi, synthetic
+
+pytestmark = pytest.mark.gpu
+P = C.POINTER
+
+
+class Runner:
+    def __init__(self, dev, use_desc):
+        import torch
+        self.torch, self.dev, self.use_desc = torch, dev, use_desc
+        self.L = badslam_amd.lib()
+        self.ctx = badslam_amd.Context(0)
+        badslam_amd.check(self.L.bslam_set_keyframe_cache(self.ctx.handle, 1))
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.K = dev.stack.K
+        self.kfs = dev.keyframe_views()
+        self.cam = dev.stack.camera
+
+    def coeffs(self, surfels=None, size=None):
+        surfels = self.dev.surfels if surfels is None else surfels
+        size = surfels.shape[1] if size is None else size
+        dp, sb = self.dev.depth_params(), self.dev.buf(surfels)
+        Hb = np.zeros((self.K, 27), np.float32)
+        counts = np.zeros(self.K, np.uint32)
+        badslam_amd.check(self.L.bslam_accumulate_pose_coeffs_batched(
+            self.ctx.handle, self.stream, 1, int(self.use_desc), C.byref(self.cam), C.byref(self.cam), C.byref(dp), self.K, self.kfs, size, C.byref(sb),
+            Hb.ctypes.data_as(P(C.c_float)), counts.ctypes.data_as(P(C.c_uint32))))
+        return Hb, counts
+
+    def activation(self):
+        dp, sb, ab = self.dev.depth_params(), self.dev.buf(self.dev.surfels), self.dev.buf(self.dev.active)
+        badslam_amd.check(self.L.bslam_update_surfel_activation(self.ctx.handle, self.stream, C.byref(self.cam), C.byref(dp), self.K, self.kfs,
+                                                                self.dev.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+        return self.dev.active[0, :self.dev.surfels_size].clone()
+
+    def geometry(self):
+        dp, sb, ab = self.dev.depth_params(), self.dev.buf(self.dev.surfels), self.dev.buf(self.dev.active)
+        badslam_amd.check(self.L.bslam_optimize_geometry_iteration(self.ctx.handle, self.stream, 1, int(self.use_desc), C.byref(self.cam), C.byref(self.cam),
+                                                                   C.byref(dp), self.K, self.kfs, self.dev.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+
+
+def check_additive_and_deterministic(run, rel):
+    S = run.dev.surfels_size
+    full, cnt = run.coeffs()
+    again, cnt2 = run.coeffs()
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32)) and np.array_equal(cnt, cnt2), "two runs must agree bit for bit"
+    cut = (S // 3) & ~255
+    a, ca = run.coeffs(run.dev.surfels[:, :cut].contiguous())
+    b, cb = run.coeffs(run.dev.surfels[:, cut:].contiguous())
+    assert np.array_equal(ca.astype(np.uint64) + cb, cnt.astype(np.uint64)), "residual counts are integers: exactly additive over shards"
+    assert cnt.min() > 1000
+    scale = np.abs(full.astype(np.float64)).max(axis=1, keepdims=True)
+    err = np.abs(a.astype(np.float64) + b - full) / scale
+    assert err.max() <= rel, err.max()
+    return full, cnt
+
+
+def test_configs2_photometric_300_keyframes_properties_and_oracle(oracle):
+    """configs[2] size: 300 keyframes, 5.76 M surfels, depth + descriptor residuals."""
+    import torch
+    from tests import bso
+    K = 300
+    dev = synthetic.TorchStack(K, "cuda:0")
+    assert dev.surfels_size == 19200 * K
+    run = Runner(dev, use_desc=True)
+    # descriptors: two BA geometry iterations fit them to the images (they start at 0); activation is idempotent
+    act = run.activation()
+    assert int(act.sum()) > 0.99 * dev.surfels_size
+    run.geometry()
+    assert torch.equal(run.activation(), act)
+    run.geometry()
+    assert float(dev.surfels[6, :dev.surfels_size].abs().max()) > 1.0          # descriptors moved off zero
+    full, cnt = check_additive_and_deterministic(run, 1e-4)
+    # oracle on three keyframes (first, middle, last), all 5.76 M surfels each, on the data copied back from the device
+    L = bso.lib()
+    surf = np.ascontiguousarray(dev.surfels.cpu().numpy())
+    sb = bso.np_buffer2d(surf)
+    cf = bso.np_buffer2d(dev.stack.cfactor)
+    dp = abi.DepthParams(cf, 0.0, float(dev.stack.raw_to_float_depth), dev.stack.baseline_fx, dev.stack.cell)
+    for k in (0, 149, 299):
+        depth, normals, radius, color = dev.host_keyframe(k)
+        _, M, _ = dev.stack.pose(k)
+        H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+        H64, b64 = np.zeros(21, np.float64), np.zeros(6, np.float64)
+        count, cost = C.c_uint32(), C.c_float()
+        L.bso_accumulate_pose_estimation_coeffs(1, 1, C.byref(dev.stack.camera), C.byref(dev.stack.camera), C.byref(dp), C.byref(bso.np_buffer2d(depth)),
+                                                C.byref(bso.np_buffer2d(normals)), C.byref(bso.np_buffer2d(color)), C.byref(M), dev.surfels_size, C.byref(sb),
+                                                abi.TEX_FIXED_POINT_1_8, C.byref(count), C.byref(cost), bso.fptr(H), bso.fptr(b),
+                                                H64.ctypes.data_as(P(C.c_double)), b64.ctypes.data_as(P(C.c_double)), None)
+        assert count.value == cnt[k], (k, count.value, cnt[k])
+        assert np.abs(full[k, :21] - H64).max() <= 1e-4 * np.abs(H64).max(), k
+        assert np.abs(full[k, 21:27] - b64).max() <= 1e-4 * max(np.abs(b64).max(), 1e-3 * np.abs(H64).max()), k
+
+
+def test_configs4_geometry_1000_keyframes_20m_surfels_properties():
+    """configs[4] size on one GPU: 1000 keyframes, 19.2 M surfels, depth residuals only (3.1 GB of keyframe images, 2.5 GB of
+    derived records, 1.3 GB of surfels: 288 GB of HBM make the 8-GPU workload a single-card case)."""
+    import torch
+    K = 1000
+    dev = synthetic.TorchStack(K, "cuda:0")
+    assert dev.surfels_size == 19200 * K
+    run = Runner(dev, use_desc=False)
+    act = run.activation()
+    assert int(act.sum()) > 0.99 * dev.surfels_size
+    assert torch.equal(run.activation(), act)
+    check_additive_and_deterministic(run, 1e-4)
+    # geometry iteration: keyframe chunks of 128 (default) vs one launch over the 1000 keyframes, bit-identical
+    start = dev.surfels.clone()
+    run.geometry()
+    chunked = dev.surfels[:8].clone()
+    dev.surfels.copy_(start)
+    badslam_amd.check(run.L.bslam_set_geometry_keyframe_chunk(run.ctx.handle, 0))
+    run.geometry()
+    assert torch.equal(dev.surfels[:8].view(torch.int32), chunked.view(torch.int32))
+    assert not torch.equal(chunked[:3], start[:3])
