@@ -415,14 +415,17 @@ struct DescSamples {
 __device__ __forceinline__ DescSamples descriptor_samples_issue(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2) {
   DescSamples d;
   const f2 pts[3] = {cp, t1, t2};
+  // Inside the image the gradient's footprint (BS/cost_function.cuh:200-211: ix = int(max(0, x - 0.5)), tx = clamp(x - 0.5 - ix, 0, 1))
+  // IS the sample's: ix = floor(x - 0.5) and tx = the unquantised fraction, bit for bit (the same subtraction); only the
+  // half-pixel border strip needs the general form (one rarely taken block for all three samples).
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     d.f[k] = tex_footprint(c, pts[k].x, pts[k].y);
-    // Inside the image the gradient's footprint (BS/cost_function.cuh:200-211: ix = int(max(0, x - 0.5)), tx = clamp(x - 0.5 - ix, 0, 1))
-    // IS the sample's: ix = floor(x - 0.5) and tx = the unquantised fraction, bit for bit (the same subtraction); only the
-    // half-pixel border strip needs the general form.
     d.g[k].ix = d.f[k].i; d.g[k].iy = d.f[k].j; d.g[k].tx = d.f[k].ua; d.g[k].ty = d.f[k].ub;
-    if (!d.f[k].interior) d.g[k] = grad_footprint(c, pts[k]);
+  }
+  if (!(d.f[0].interior & d.f[1].interior & d.f[2].interior)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.g[k] = grad_footprint(c, pts[k]);
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) d.q[k] = quad_at(kf, c, d.f[k].i, d.f[k].j);
@@ -434,10 +437,14 @@ __device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const LumaQuad t = unpack_quad_bytes(d.q[k]);
-    LumaQuad tg = t;
-    if (d.g[k].ix != d.f[k].i || d.g[k].iy != d.f[k].j) tg = unpack_quad_bytes(quad_at(kf, c, d.g[k].ix, d.g[k].iy));   // only in the half-pixel border strip
     val[k] = bilinear_bytes(t, d.f[k].a, d.f[k].b);
-    bilinear_gradient_bytes(tg, d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
+    bilinear_gradient_bytes(t, d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
+  }
+  // only in the half-pixel border strip does a gradient read another quad than its sample
+  if ((d.g[0].ix != d.f[0].i) | (d.g[0].iy != d.f[0].j) | (d.g[1].ix != d.f[1].i) | (d.g[1].iy != d.f[1].j) | (d.g[2].ix != d.f[2].i) | (d.g[2].iy != d.f[2].j)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      bilinear_gradient_bytes(unpack_quad_bytes(quad_at(kf, c, d.g[k].ix, d.g[k].iy)), d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
   }
   *r1 = __builtin_fmaf(kDescScale, val[1] - val[0], -d1);
   *r2 = __builtin_fmaf(kDescScale, val[2] - val[0], -d2);

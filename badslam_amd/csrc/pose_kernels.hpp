@@ -32,6 +32,9 @@ constexpr int kPoseThreads = 256;
 #ifndef BSLAM_POSE_R_DESC
 #define BSLAM_POSE_R_DESC 2
 #endif
+#ifndef BSLAM_POSE_PREFETCH
+#define BSLAM_POSE_PREFETCH 0
+#endif
 constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
 constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
 constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
@@ -120,10 +123,25 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
     uint32_t count = 0;
 
+#if BSLAM_POSE_PREFETCH
+    // The record gathers of all kPoseR surfels are issued up front (the cheap projection is simply evaluated twice), so that
+    // only the first one's latency is exposed: the others arrive while the earlier surfels are being processed.
+    uint2 pre[kPoseR];
+#pragma unroll
+    for (int r = 0; r < kPoseR; ++r) {
+      Proj q;
+      pre[r] = make_uint2(0u, (uint32_t)BSLAM_INVALID_DEPTH_BIT << 16);
+      if (valid[r] && project_to_pixel(c, kf, gp[r], &q)) pre[r] = load_record(c, kf, q);
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < kPoseR; ++r) {
       Proj p;
+#if BSLAM_POSE_PREFETCH
+      if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p) || !associate_with_record(c, kf, gn[r], pre[r], &p)) continue;
+#else
       if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+#endif
       float J[6];
       float raw;
       if (kDepth) {                                           // BS/kernel_opt_pose.cu:283-317
