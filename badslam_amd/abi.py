@@ -115,6 +115,15 @@ SIGNATURES = {
     "bslam_compute_cost_and_residual_count_from_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), C.c_float,
                                                                    C.c_float, P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Mat3x4), P(Buffer2D),
                                                                    P(Buffer2D), P(Buffer2D), P(C.c_uint32), P(C.c_float)]),
+    "bslam_accumulate_pose_coeffs_from_images_gradmag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), C.c_float, C.c_float,
+                                                                  P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Mat3x4), P(Buffer2D), P(Buffer2D), P(Buffer2D),
+                                                                  P(C.c_uint32), P(C.c_float), P(C.c_float)]),
+    "bslam_compute_cost_and_residual_count_from_images_gradmag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(Camera4f), P(Camera4f), C.c_float,
+                                                                           C.c_float, P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Mat3x4), P(Buffer2D),
+                                                                           P(Buffer2D), P(Buffer2D), P(C.c_uint32), P(C.c_float)]),
+    "bslam_compute_sobel_gradient_magnitude": (C.c_int, [C.c_void_p, C.c_void_p, P(Buffer2D), P(Buffer2D)]),
+    "bslam_calibrate_and_downsample_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(DepthParams), P(Buffer2D), P(Buffer2D), P(Buffer2D), P(Buffer2D),
+                                                       P(Buffer2D), P(Buffer2D)]),
     "bslam_compact_surfels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, P(C.c_uint32), P(Buffer2D), P(Buffer2D)]),
     "bslam_invalidate_keyframe_cache": (C.c_int, [C.c_void_p]),
     "bslam_comm_get_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),

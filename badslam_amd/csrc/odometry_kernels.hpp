@@ -95,6 +95,61 @@ __global__ __launch_bounds__(256) void downsample_kernel(Img depth, Img normals,
   }
   out_color.at<uint8_t>(y, x) = sat_u8(255.f * tex_u8_direct(color, 2 * x + 1.0f, 2 * y + 1.0f, tex_mode) + 0.5f);
 }
+// ComputeSobelGradientMagnitudeKernel(texture, gradmag) BS/cuda_image_processing.cu:104-143: Sobel magnitude of the luma channel
+// (.w of the uchar4 image, clamp addressing), normalised to 0..255 and truncated
+__global__ __launch_bounds__(256) void sobel_gradient_magnitude_kernel(Img color, Img out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= out.width || y >= out.height) return;
+  float I[3][3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int ix = max(0, min(x + dx, color.width - 1)), iy = max(0, min(y + dy, color.height - 1));
+      I[dy + 1][dx + 1] = 255.f * ((float)(color.at<uint32_t>(iy, ix) >> 24) * (1.0f / 255.0f));   // 255 * tex2D<float4>(...).w at a texel centre
+    }
+  const float gx = 1 * I[0][2] - 1 * I[0][0] + 2 * I[1][2] - 2 * I[1][0] + 1 * I[2][2] - 1 * I[2][0];
+  const float gy = 1 * I[2][0] - 1 * I[0][0] + 2 * I[2][1] - 2 * I[0][1] + 1 * I[2][2] - 1 * I[0][2];
+  constexpr float kNormalizer = 255.99f / (1.41421356237309504880f * 4 * 255.f);
+  out.at<uint8_t>(y, x) = sat_u8(kNormalizer * sqrtf(gx * gx + gy * gy));
+}
+// CalibrateAndDownsampleImagesCUDAKernel<downsample_color> BS/kernel_downsample.cu:40-105: first pyramid step of a tracked frame whose
+// level 0 is not used (the cfactor cell is looked up with the DOWNSAMPLED pixel coordinates, as in the reference, :65-66)
+template <bool kDownsampleColor>
+__global__ __launch_bounds__(256) void calibrate_and_downsample_kernel(CamConsts c, Img depth_u16, Img normals, Img color, Img out_depth, Img out_normals, Img out_color) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= out_depth.width || y >= out_depth.height) return;
+  float depths[4], depth_sum = 0.f;
+  int depth_count = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t raw = depth_u16.at<uint16_t>(2 * y + (i >> 1), 2 * x + (i & 1));
+    if (!(raw & BSLAM_INVALID_DEPTH_BIT)) {
+      const float cf = *(const float*)((const uint8_t*)c.cfactor + (size_t)(y / c.cell) * c.cfactor_pitch + 4 * (size_t)(x / c.cell));
+      depths[i] = raw_to_calibrated_depth(c.a, cf, c.raw_to_float_depth, raw);
+      depth_sum += depths[i];
+      depth_count += 1;
+    } else {
+      depths[i] = __uint_as_float(0x7f800000u);
+    }
+  }
+  if (depth_count == 0) {
+    out_depth.at<float>(y, x) = 0.f;
+  } else {
+    const float average_depth = depth_sum / (float)depth_count;
+    int closest_index = 0;
+    float closest_distance = __uint_as_float(0x7f800000u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float distance = fabsf(depths[i] - average_depth);
+      if (distance < closest_distance) { closest_index = i; closest_distance = distance; }
+    }
+    out_depth.at<float>(y, x) = depths[closest_index];
+    out_normals.at<uint16_t>(y, x) = normals.at<uint16_t>(2 * y + (closest_index >> 1), 2 * x + (closest_index & 1));
+  }
+  const float col = kDownsampleColor ? tex_u8_direct(color, 2 * x + 1.0f, 2 * y + 1.0f, c.tex_mode) : tex_u8_direct(color, x + 0.5f, y + 0.5f, c.tex_mode);
+  out_color.at<uint8_t>(y, x) = sat_u8(255.f * col + 0.5f);
+}
 // luma quads of a u8 image (see KfDev::quads)
 __global__ __launch_bounds__(256) void build_quads_u8_kernel(Img img, uint32_t* __restrict__ quads) {
   const int qx = blockIdx.x * blockDim.x + threadIdx.x, qy = blockIdx.y;
@@ -109,12 +164,15 @@ struct PairImages {
   Img surfel_depth, surfel_normals, surfel_color;   // base frame: f32 depth, u16 normals, u8 colour (depth intrinsics)
   Img frame_depth, frame_normals;                   // tracked frame: f32 depth, u16 normals
   const uint32_t* frame_quads;                      // tracked frame colour as luma quads (colour intrinsics)
+  Img frame_color;                                  // the same image, direct (the gradient-magnitude variant reads it as the reference does)
 };
 
 // One thread per base pixel.  kCoeffs: H (21) + b (6) of AccumulatePoseEstimationCoeffsFromImagesCUDAKernel_GradientXY
 // (column 28 = number of visible pixels); !kCoeffs: cost (column 27) and residual count (column 28) of
 // ComputeCostAndResidualCountFromImagesCUDAKernel_GradientXY.
-template <bool kDepth, bool kDesc, bool kCoeffs>
+// kGradMag: ONE colour residual on gradient-magnitude images (ComputeRawColorResidualAndJacobian BS/kernel_opt_pose.cu:192-222,
+// kernels :713-937 and :1173-1338) instead of the two descriptor residuals.
+template <bool kDepth, bool kDesc, bool kCoeffs, bool kGradMag = false>
 __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T, float threshold_factor, PairImages im, float* __restrict__ partials) {
   const int pixel = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = im.surfel_depth.width, h = im.surfel_depth.height;
@@ -157,7 +215,28 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
       raw_depth = depth_residual(inv_stddev, n_local, lu, local);
       depth_pose_jacobian(inv_stddev, n_local, lu, Jd);
     }
-    if (visible && kDesc) {
+    if (visible && kDesc && kGradMag) {
+      f2 cp;
+      if (depth_to_color_pxy(c, pxy, &cp)) {
+        r1 = 255.f * tex_u8_direct(im.frame_color, cp.x, cp.y, c.tex_mode) - (float)im.surfel_color.at<uint8_t>(y, x);   // BS/cost_function.cuh:324-331
+        if (kCoeffs) {                                                                                                    // :335-352
+          const GradFootprint g = grad_footprint(c, cp);
+          auto texel = [&](int ix, int iy) {
+            ix = max(0, min(ix, im.frame_color.width - 1));
+            iy = max(0, min(iy, im.frame_color.height - 1));
+            return 255.f * ((float)im.frame_color.at<uint8_t>(iy, ix) * (1.0f / 255.0f));
+          };
+          const LumaQuad q{texel(g.ix, g.iy), texel(g.ix + 1, g.iy), texel(g.ix, g.iy + 1), texel(g.ix + 1, g.iy + 1)};
+          float gx, gy;
+          grad_filter(q, g, &gx, &gy);
+          gx *= c.cfx;
+          gy *= c.cfy;
+          descriptor_pose_jacobian<true>(gx, gy, local, J1);
+        }
+      } else {
+        visible = false;
+      }
+    } else if (visible && kDesc) {
       if (x < w - 1 && y < h - 1) {
         const float intensity = 1 / 255.f * (float)im.surfel_color.at<uint8_t>(y, x);
         const float t1_intensity = 1 / 255.f * (float)im.surfel_color.at<uint8_t>(y, x + 1);
@@ -199,11 +278,14 @@ __global__ __launch_bounds__(256) void pair_accumulate_kernel(CamConsts c, M34 T
         if (kDepth) accumulate_h_b(raw_depth, 1.f * tukey_weight(raw_depth, threshold_factor * kDepthTukey), Jd, acc);
         if (kDesc) {
           accumulate_h_b(r1, threshold_factor * kDescWeight * huber_weight(r1, kDescHuber), J1, acc);
-          accumulate_h_b(r2, threshold_factor * kDescWeight * huber_weight(r2, kDescHuber), J2, acc);
+          if (!kGradMag) accumulate_h_b(r2, threshold_factor * kDescWeight * huber_weight(r2, kDescHuber), J2, acc);
         }
       } else {
         if (kDepth) { count += 1; acc[kRowCost] += 1.f * tukey_residual(raw_depth, threshold_factor * kDepthTukey); }
-        if (kDesc) {
+        if (kDesc && kGradMag) {
+          count += 1;
+          acc[kRowCost] += threshold_factor * kDescWeight * huber_residual(r1, kDescHuber);
+        } else if (kDesc) {
           count += 2;
           acc[kRowCost] += threshold_factor * kDescWeight * huber_residual(r1, kDescHuber);
           acc[kRowCost] += threshold_factor * kDescWeight * huber_residual(r2, kDescHuber);

@@ -256,17 +256,18 @@ class DirectBA:
                                                    color.ctypes.data_as(C.POINTER(C.c_uint8)), _f(mm)))
         return depth, normals, radius, color, float(mm[0]), float(mm[1])
 
-    def TrackKeyframePair(self, tracked_id, base_id, init1, init2=None, num_scales=5, test_different_initial_estimates=False):
+    def TrackKeyframePair(self, tracked_id, base_id, init1, init2=None, num_scales=5, test_different_initial_estimates=False,
+                          use_pyramid_level_0=True, use_gradmag=False):
         """TrackFramePairwise (BS/pairwise_frame_tracking.cc:256-678) of keyframe `tracked_id` against keyframe `base_id`:
         returns (base_T_tracked, iterations per scale)."""
-        self.L.bsh_track_keyframe_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                                   C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        self.L.bsh_track_keyframe_pair_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                      C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.c_int]
         out = np.zeros(7, np.float32)
         its = (C.c_int * num_scales)()
         p1 = pose7(init1)
         p2 = pose7(init2 if init2 is not None else init1)
-        self._check(self.L.bsh_track_keyframe_pair(self._ba, self.stream, tracked_id, base_id, num_scales, int(test_different_initial_estimates), _f(p1), _f(p2),
-                                                   _f(out), its))
+        self._check(self.L.bsh_track_keyframe_pair_ex(self._ba, self.stream, tracked_id, base_id, num_scales, int(test_different_initial_estimates), _f(p1),
+                                                      _f(p2), _f(out), its, int(use_pyramid_level_0), int(use_gradmag)))
         return se3f_from7(out), list(its)
 
     def SaveState(self, path, frame_count):

@@ -418,6 +418,25 @@ int bsh_state_load_into_ba(void* ba_, void* stream_, const char* path) {
 
 // TrackFramePairwise on two keyframes of a DirectBA (base = the reference keyframe, tracked = the frame to localise):
 // out = base_T_tracked.  iterations: num_scales ints (may be null).
+int bsh_track_keyframe_pair_ex(void* ba_, void* stream, int tracked_id, int base_id, int num_scales, int test_different_initial_estimates,
+                               const float* init1_pose7, const float* init2_pose7, float* out_pose7, int* iterations, int use_pyramid_level_0, int use_gradmag) {
+  BSH_TRY({
+    DirectBA* ba = static_cast<DirectBA*>(ba_);
+    const auto& tracked = ba->keyframes().at(tracked_id);
+    const auto& base = ba->keyframes().at(base_id);
+    PairwiseFrameTrackingBuffers buffers(ba->depth_camera().width(), ba->depth_camera().height(), ba->color_camera().width(), ba->color_camera().height(),
+                                         num_scales);
+    SE3f out;
+    const bslam_depth_params dp = ba->depth_params();
+    for (int s = 0; s < num_scales; ++s) iterations[s] = 0;
+    TrackFramePairwise(ba->context(), static_cast<hipStream_t>(stream), &buffers, ba->color_camera(), ba->depth_camera(), dp, ba->use_depth_residuals(),
+                       ba->use_descriptor_residuals(), tracked->depth_buffer(), tracked->normals_buffer(), tracked->color_buffer(), base->depth_buffer(),
+                       base->normals_buffer(), base->color_buffer(), test_different_initial_estimates != 0, pose_from7(init1_pose7),
+                       pose_from7(init2_pose7 ? init2_pose7 : init1_pose7), &out, iterations, use_pyramid_level_0 != 0, use_gradmag != 0);
+    pose_to7(out, out_pose7);
+  });
+}
+
 int bsh_track_keyframe_pair(void* ba_, void* stream, int tracked_id, int base_id, int num_scales, int test_different_initial_estimates,
                             const float* init1_pose7, const float* init2_pose7, float* out_pose7, int* iterations) {
   BSH_TRY({

@@ -51,7 +51,8 @@ void TrackFramePairwise(bslam_context* ctx, hipStream_t stream, PairwiseFrameTra
                         const PinholeCamera4f& depth_camera, const bslam_depth_params& dp, bool use_depth_residuals, bool use_descriptor_residuals,
                         const DeviceBuffer<u16>& tracked_depth_u16, const DeviceBuffer<u16>& tracked_normals_l0, const DeviceBuffer<uchar4_t>& tracked_color_rgba,
                         const DeviceBuffer<u16>& base_depth_u16, const DeviceBuffer<u16>& base_normals_l0, const DeviceBuffer<uchar4_t>& base_color_rgba,
-                        bool test_different_initial_estimates, const SE3f& init1, const SE3f& init2, SE3f* out_base_T_frame, int* iterations_per_scale) {
+                        bool test_different_initial_estimates, const SE3f& init1, const SE3f& init2, SE3f* out_base_T_frame, int* iterations_per_scale,
+                        bool use_pyramid_level_0, bool use_gradmag) {
   if (depth_camera.width() != color_camera.width()) throw std::invalid_argument("TrackFramePairwise: depth and colour images must have the same size here");
   const int num_scales = buffers->num_scales;
   const bslam_camera4f color_cam = color_camera.pod(), depth_cam = depth_camera.pod();
@@ -69,32 +70,45 @@ void TrackFramePairwise(bslam_context* ctx, hipStream_t stream, PairwiseFrameTra
   const bslam_buffer2d base_rgba = base_color_rgba.ToPod(), tracked_rgba = tracked_color_rgba.ToPod();
   const bslam_buffer2d base_gm = buffers->base_gradmag->ToPod(), tracked_gm = buffers->tracked_gradmag->ToPod();
   const bslam_buffer2d base_d16 = base_depth_u16.ToPod(), tracked_d16 = tracked_depth_u16.ToPod();
-  Check(bslam_compute_brightness_from_color(ctx, stream, &base_rgba, &base_gm), "bslam_compute_brightness_from_color");
+  // gradient-magnitude images instead of brightness images when use_gradmag (:859-869, 888-898)
+  auto colour_cue = [&](const bslam_buffer2d* rgba, const bslam_buffer2d* out) {
+    if (use_gradmag) Check(bslam_compute_sobel_gradient_magnitude(ctx, stream, rgba, out), "bslam_compute_sobel_gradient_magnitude");
+    else Check(bslam_compute_brightness_from_color(ctx, stream, rgba, out), "bslam_compute_brightness_from_color");
+  };
+  colour_cue(&base_rgba, &base_gm);
   Check(bslam_calibrate_depth_and_transform_color_to_depth(ctx, stream, &color_cam, &depth_cam, &dp, &base_d16, &base_gm, &base_depth[0], &base_color[0]),
         "bslam_calibrate_depth_and_transform_color_to_depth");
-  Check(bslam_compute_brightness_from_color(ctx, stream, &tracked_rgba, &tracked_gm), "bslam_compute_brightness_from_color");
+  colour_cue(&tracked_rgba, &tracked_gm);
   // --- pyramids (BS/pairwise_frame_tracking.cc:283-341)
-  Check(bslam_calibrate_depth(ctx, stream, &dp, &tracked_d16, &tracked_depth[0]), "bslam_calibrate_depth");
-  Check(bslam_set_to_read_mode_normalized(ctx, stream, &tracked_gm, &tracked_color[0]), "bslam_set_to_read_mode_normalized");
+  const bslam_buffer2d tracked_normals_in = tracked_normals_l0.ToPod();
+  if (use_pyramid_level_0) {
+    Check(bslam_calibrate_depth(ctx, stream, &dp, &tracked_d16, &tracked_depth[0]), "bslam_calibrate_depth");
+    Check(bslam_set_to_read_mode_normalized(ctx, stream, &tracked_gm, &tracked_color[0]), "bslam_set_to_read_mode_normalized");
+  } else if (num_scales > 1) {   // :303-323
+    Check(bslam_calibrate_and_downsample_images(ctx, stream, depth_camera.width() == color_camera.width(), &dp, &tracked_d16, &tracked_normals_in, &tracked_gm,
+                                                &tracked_depth[1], &tracked_normals[1], &tracked_color[1]),
+          "bslam_calibrate_and_downsample_images");
+  }
   for (int s = 1; s < num_scales; ++s) {
-    Check(bslam_downsample_images(ctx, stream, &tracked_depth[s - 1], &tracked_normals[s - 1], &tracked_color[s - 1], &tracked_depth[s], &tracked_normals[s],
-                                  &tracked_color[s]),
-          "bslam_downsample_images");
+    if (s >= 2 || use_pyramid_level_0)
+      Check(bslam_downsample_images(ctx, stream, &tracked_depth[s - 1], &tracked_normals[s - 1], &tracked_color[s - 1], &tracked_depth[s], &tracked_normals[s],
+                                    &tracked_color[s]),
+            "bslam_downsample_images");
     Check(bslam_downsample_images(ctx, stream, &base_depth[s - 1], &base_normals[s - 1], &base_color[s - 1], &base_depth[s], &base_normals[s], &base_color[s]),
           "bslam_downsample_images");
   }
   // --- coarse to fine (:343-640)
   constexpr int kMaxIterationsPerScale = 30;
   SE3f estimate = init1, chosen_initial = init1;
-  for (int scale = num_scales - 1; scale >= 0; --scale) {
+  for (int scale = num_scales - 1; scale >= (use_pyramid_level_0 ? 0 : 1); --scale) {   // :367
     const float scaling_factor = static_cast<float>(std::pow(2, scale));
     const bslam_camera4f tcc = Scaled(color_camera, 1.f / scaling_factor), tdc = Scaled(depth_camera, 1.f / scaling_factor);
     const float threshold_factor = scaling_factor;
     auto cost_of = [&](const SE3f& base_T_frame, u32* count, float* cost) {
       const bslam_mat3x4 M = base_T_frame.Inverse().Matrix3x4();
-      Check(bslam_compute_cost_and_residual_count_from_images(ctx, stream, use_depth_residuals, use_descriptor_residuals, &tcc, &tdc, dp.baseline_fx,
-                                                              threshold_factor, &tracked_depth[scale], &tracked_normals[scale], &tracked_color[scale], &M,
-                                                              &base_depth[scale], &base_normals[scale], &base_color[scale], count, cost),
+      Check((use_gradmag ? bslam_compute_cost_and_residual_count_from_images_gradmag : bslam_compute_cost_and_residual_count_from_images)(
+                ctx, stream, use_depth_residuals, use_descriptor_residuals, &tcc, &tdc, dp.baseline_fx, threshold_factor, &tracked_depth[scale],
+                &tracked_normals[scale], &tracked_color[scale], &M, &base_depth[scale], &base_normals[scale], &base_color[scale], count, cost),
             "bslam_compute_cost_and_residual_count_from_images");
     };
     if (scale != num_scales - 1 || test_different_initial_estimates) {   // :428-489
@@ -114,9 +128,9 @@ void TrackFramePairwise(bslam_context* ctx, hipStream_t stream, PairwiseFrameTra
     for (iteration = 0; iteration < kMaxIterationsPerScale; ++iteration) {
       const bslam_mat3x4 M = estimate.Inverse().Matrix3x4();
       float H[21], b[6], x[6];
-      Check(bslam_accumulate_pose_coeffs_from_images(ctx, stream, use_depth_residuals, use_descriptor_residuals, &tcc, &tdc, dp.baseline_fx, threshold_factor,
-                                                     &tracked_depth[scale], &tracked_normals[scale], &tracked_color[scale], &M, &base_depth[scale],
-                                                     &base_normals[scale], &base_color[scale], nullptr, H, b),
+      Check((use_gradmag ? bslam_accumulate_pose_coeffs_from_images_gradmag : bslam_accumulate_pose_coeffs_from_images)(
+                ctx, stream, use_depth_residuals, use_descriptor_residuals, &tcc, &tdc, dp.baseline_fx, threshold_factor, &tracked_depth[scale],
+                &tracked_normals[scale], &tracked_color[scale], &M, &base_depth[scale], &base_normals[scale], &base_color[scale], nullptr, H, b),
             "bslam_accumulate_pose_coeffs_from_images");
       SolveLDLTUpper(6, H, b, x);   // :561
       float damping = 1.f;          // :573-579

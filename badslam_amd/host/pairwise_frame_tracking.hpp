@@ -1,7 +1,7 @@
 // pairwise_frame_tracking.hpp -- host side of the odometry: the coarse-to-fine direct alignment
 // of a tracked frame against a base keyframe.  Mirrors vis::TrackFramePairwise (BS/pairwise_frame_tracking.cc:256-678)
-// with use_pyramid_level_0 = true, use_gradmag = false, plus the input preparation BadSlam::RunOdometry does before the
-// call (BS/bad_slam.cc:859-897).  The kernels are behind the C ABI (include/badslam_hip.h, odometry section).
+// with both of its switches (use_pyramid_level_0, use_gradmag; BadSlam::RunOdometry passes true / false), plus the input
+// preparation BadSlam::RunOdometry does before the call (BS/bad_slam.cc:859-897).  The kernels are behind the C ABI (include/badslam_hip.h, odometry section).
 #pragma once
 
 #include <memory>
@@ -28,6 +28,7 @@ void TrackFramePairwise(bslam_context* ctx, hipStream_t stream, PairwiseFrameTra
                         bool use_descriptor_residuals, const DeviceBuffer<u16>& tracked_depth, const DeviceBuffer<u16>& tracked_normals,
                         const DeviceBuffer<uchar4_t>& tracked_color, const DeviceBuffer<u16>& base_depth, const DeviceBuffer<u16>& base_normals,
                         const DeviceBuffer<uchar4_t>& base_color, bool test_different_initial_estimates, const SE3f& base_T_frame_initial_estimate_1,
-                        const SE3f& base_T_frame_initial_estimate_2, SE3f* out_base_T_frame, int* iterations_per_scale);
+                        const SE3f& base_T_frame_initial_estimate_2, SE3f* out_base_T_frame, int* iterations_per_scale,
+                        bool use_pyramid_level_0 = true, bool use_gradmag = false);
 
 }  // namespace bslam_host

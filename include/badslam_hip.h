@@ -499,6 +499,33 @@ int bslam_compute_cost_and_residual_count_from_images(
     const bslam_mat3x4* estimate_frame_T_surfel_frame,
     const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color,
     uint32_t* residual_count, float* residual_sum);
+/* The use_gradmag = true branch of the two functions above (BS/kernel_opt_pose.cc:121-135, 212-221; kernels
+ * BS/kernel_opt_pose.cu:713-937, 1173-1338): ONE colour residual per pixel, 255 x tex(tracked gradient magnitude) - base gradient
+ * magnitude, on images produced by bslam_compute_sobel_gradient_magnitude instead of the brightness images. */
+int bslam_accumulate_pose_coeffs_from_images_gradmag(
+    bslam_context* ctx, void* stream, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* downsampled_depth, const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color,
+    uint32_t* visible_count, float* H, float* b);
+int bslam_compute_cost_and_residual_count_from_images_gradmag(
+    bslam_context* ctx, void* stream, int use_depth_residuals, int use_descriptor_residuals,
+    const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, float baseline_fx, float threshold_factor,
+    const bslam_buffer2d* downsampled_depth, const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color,
+    const bslam_mat3x4* estimate_frame_T_surfel_frame,
+    const bslam_buffer2d* surfel_depth, const bslam_buffer2d* surfel_normals, const bslam_buffer2d* surfel_color,
+    uint32_t* residual_count, float* residual_sum);
+/* Replaces ComputeSobelGradientMagnitudeCUDA(stream, rgbi_texture, gradmag_buffer) (BS/cuda_image_processing.cu:104-167): Sobel
+ * gradient magnitude of the luma channel of a uchar4 colour image, 0..255. */
+int bslam_compute_sobel_gradient_magnitude(bslam_context* ctx, void* stream, const bslam_buffer2d* color_buffer, const bslam_buffer2d* gradmag_buffer);
+/* Replaces CalibrateAndDownsampleImagesCUDA (BS/kernels.h:355-366, BS/kernel_downsample.cu:40-105, 237-270): first pyramid step of
+ * a tracked frame whose level 0 is not used (use_pyramid_level_0 = false): u16 raw depth -> calibrated float depth at half
+ * resolution; downsample_color = 0 when the colour image already has half the depth image's resolution. */
+int bslam_calibrate_and_downsample_images(
+    bslam_context* ctx, void* stream, int downsample_color, const bslam_depth_params* depth_params,
+    const bslam_buffer2d* depth_buffer, const bslam_buffer2d* normals_buffer, const bslam_buffer2d* color_u8,
+    const bslam_buffer2d* downsampled_depth, const bslam_buffer2d* downsampled_normals, const bslam_buffer2d* downsampled_color);
 
 /* Multi-GPU (surfel-sharded) runs of the PCG and intrinsics entry points: every rank holds its own
  * surfel shard and the full keyframe list; `allreduce` sums a device buffer of floats in place across

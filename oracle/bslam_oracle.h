@@ -218,6 +218,12 @@ void bso_downsample_images(const bslam_buffer2d* depth, const bslam_buffer2d* no
                            const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals, const bslam_buffer2d* out_color);
 /* out: [num_scales][6] images {base depth f32, base normals u16, base colour u8, tracked depth, normals, colour};
  * free with bso_free_tracking_pyramids */
+void bso_compute_sobel_gradient_magnitude(const bslam_buffer2d* color_uchar4, const bslam_buffer2d* out_u8);
+void bso_calibrate_and_downsample_images(int downsample_color, const bslam_depth_params* dp, const bslam_buffer2d* depth_u16, const bslam_buffer2d* normals,
+                                         const bslam_buffer2d* color_u8, int tex_mode, const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals,
+                                         const bslam_buffer2d* out_color);
+/* tracker variant used by the image-pair functions below and by bso_track_frame_pairwise (default: 0, 1) */
+void bso_set_tracking_variant(int use_gradmag, int use_pyramid_level_0);
 void bso_build_tracking_pyramids(
     int num_scales, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
     const bslam_buffer2d* tracked_depth_u16, const bslam_buffer2d* tracked_normals, const bslam_buffer2d* tracked_color_uchar4,

@@ -131,6 +131,77 @@ void bso_downsample_images(const bslam_buffer2d* depth, const bslam_buffer2d* no
     }
 }
 
+/* ComputeSobelGradientMagnitudeCUDA(texture, gradmag) BS/cuda_image_processing.cu:104-167: Sobel magnitude of the luma channel
+ * (.w of the uchar4 colour image read through the clamp texture at texel centres), normalised to 0..255 and truncated. */
+void bso_compute_sobel_gradient_magnitude(const bslam_buffer2d* color_uchar4, const bslam_buffer2d* out_u8) {
+  const int w = out_u8->width, h = out_u8->height;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      float I[3][3];
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int ix = x + dx, iy = y + dy;
+          if (ix < 0) ix = 0;
+          if (iy < 0) iy = 0;
+          if (ix > color_uchar4->width - 1) ix = color_uchar4->width - 1;
+          if (iy > color_uchar4->height - 1) iy = color_uchar4->height - 1;
+          const uint8_t luma = ((const uint8_t*)color_uchar4->address + (size_t)iy * color_uchar4->pitch + 4 * (size_t)ix)[3];
+          I[dy + 1][dx + 1] = 255.f * (luma * (1.0f / 255.0f));   /* 255 * tex2D<float4>(...).w at a texel centre */
+        }
+      const float gx = 1 * I[0][2] - 1 * I[0][0] + 2 * I[1][2] - 2 * I[1][0] + 1 * I[2][2] - 1 * I[2][0];
+      const float gy = 1 * I[2][0] - 1 * I[0][0] + 2 * I[2][1] - 2 * I[0][1] + 1 * I[2][2] - 1 * I[0][2];
+      const float kNormalizer = 255.99f / (1.41421356237309504880f * 4 * 255.f);
+      BSO_AT(uint8_t, out_u8, y, x) = to_u8(kNormalizer * sqrtf(gx * gx + gy * gy));
+    }
+}
+
+/* CalibrateAndDownsampleImagesCUDAKernel<downsample_color> BS/kernel_downsample.cu:40-105: the first pyramid step when the tracked
+ * frame's level 0 is not used: raw u16 depth -> calibrated float depth of the 2x2 block's member closest to the block mean.
+ * (The cfactor cell is looked up with the DOWNSAMPLED pixel coordinates, as the reference does, :65-66.) */
+void bso_calibrate_and_downsample_images(int downsample_color, const bslam_depth_params* dp, const bslam_buffer2d* depth_u16, const bslam_buffer2d* normals,
+                                         const bslam_buffer2d* color_u8, int tex_mode, const bslam_buffer2d* out_depth, const bslam_buffer2d* out_normals,
+                                         const bslam_buffer2d* out_color) {
+  static const int kOffsets[4][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}};
+  const int cell = dp->sparse_surfel_cell_size;
+  for (int y = 0; y < out_depth->height; ++y)
+    for (int x = 0; x < out_depth->width; ++x) {
+      float depths[4], depth_sum = 0;
+      int depth_count = 0;
+      for (int i = 0; i < 4; ++i) {
+        const uint16_t raw = BSO_AT(uint16_t, depth_u16, 2 * y + kOffsets[i][0], 2 * x + kOffsets[i][1]);
+        if (!(raw & BSLAM_INVALID_DEPTH_BIT)) {
+          depths[i] = bso_raw_to_calibrated_depth(dp->a, BSO_AT(float, &dp->cfactor_buffer, y / cell, x / cell), dp->raw_to_float_depth, raw);
+          depth_sum += depths[i];
+          depth_count += 1;
+        } else {
+          depths[i] = INFINITY;
+        }
+      }
+      if (depth_count == 0) {
+        BSO_AT(float, out_depth, y, x) = 0;
+      } else {
+        const float average_depth = depth_sum / depth_count;
+        int closest_index = 0;
+        float closest_distance = INFINITY;
+        for (int i = 0; i < 4; ++i) {
+          const float distance = fabsf(depths[i] - average_depth);
+          if (distance < closest_distance) { closest_index = i; closest_distance = distance; }
+        }
+        BSO_AT(float, out_depth, y, x) = depths[closest_index];
+        BSO_AT(uint16_t, out_normals, y, x) = BSO_AT(uint16_t, normals, 2 * y + kOffsets[closest_index][0], 2 * x + kOffsets[closest_index][1]);
+      }
+      const float color = downsample_color ? tex_u8(color_u8, 2 * x + 1.0f, 2 * y + 1.0f, tex_mode) : tex_u8(color_u8, x + 0.5f, y + 0.5f, tex_mode);
+      BSO_AT(uint8_t, out_color, y, x) = to_u8(255.f * color + 0.5f);
+    }
+}
+
+/* Variant switches of the tracker (the reference passes them as arguments, BS/pairwise_frame_tracking.cc:164-166):
+ * use_gradmag: ONE colour residual on gradient-magnitude images (BS/kernel_opt_pose.cu:192-222, 713-937, 1173-1338) instead of
+ * the two descriptor residuals; use_pyramid_level_0 = 0: the tracked frame enters the pyramid at level 1 through
+ * CalibrateAndDownsampleImagesCUDA and level 0 is not tracked. */
+static int g_use_gradmag = 0, g_use_pyramid_level_0 = 1;
+void bso_set_tracking_variant(int use_gradmag, int use_pyramid_level_0) { g_use_gradmag = use_gradmag != 0; g_use_pyramid_level_0 = use_pyramid_level_0 != 0; }
+
 /* ---- per-pixel evaluation shared by the coefficient and the cost kernel ---- */
 typedef struct {
   int visible;
@@ -184,7 +255,31 @@ static void evaluate_pixel(int x, int y, int use_depth, int use_desc, int need_j
     t->raw_depth_residual = bso_depth_residual(inv_stddev, n_local, lu, local);
     bso_jac_depth_pose(inv_stddev, n_local, lu, t->depth_jacobian);
   }
-  if (use_desc) {
+  if (use_desc && g_use_gradmag) {
+    /* ComputeRawColorResidualAndJacobian BS/kernel_opt_pose.cu:192-222, BS/cost_function.cuh:324-352 (the reference's expressions as
+       written in both evaluation shapes: not on the hot path) */
+    bso_f2 cp;
+    if (bso_depth_to_color_pxy(pxy, &d2c, &cp)) {
+      t->r1 = 255.f * tex_u8(frame_color, cp.x, cp.y, tex_mode) - (float)BSO_AT(uint8_t, surfel_color, y, x);
+      t->r2 = 0;
+      if (need_jacobians) {
+        int ix = bso_f2i(fmaxf(0.f, cp.x - 0.5f)), iy = bso_f2i(fmaxf(0.f, cp.y - 0.5f));
+        const float tx = fmaxf(0.f, fminf(1.f, cp.x - 0.5f - ix)), ty = fmaxf(0.f, fminf(1.f, cp.y - 0.5f - iy));
+        if (ix > frame_color->width - 1) ix = frame_color->width - 1;
+        if (iy > frame_color->height - 1) iy = frame_color->height - 1;
+        const float tl = 255.f * texel_u8(frame_color, ix, iy), tr = 255.f * texel_u8(frame_color, ix + 1, iy);
+        const float bl = 255.f * texel_u8(frame_color, ix, iy + 1), br = 255.f * texel_u8(frame_color, ix + 1, iy + 1);
+        float gx = (br - bl) * ty + (tr - tl) * (1 - ty);
+        float gy = (br - tr) * tx + (bl - tl) * (1 - tx);
+        gx *= color_camera->fx;
+        gy *= color_camera->fy;
+        bso_jac_desc_pose(gx, gy, local, t->J1);
+        for (int i = 0; i < 6; ++i) t->J2[i] = 0;
+      }
+    } else {
+      visible = 0;
+    }
+  } else if (use_desc) {
     if (x < surfel_depth->width - 1 && y < surfel_depth->height - 1) {
       const float intensity = 1 / 255.f * BSO_AT(uint8_t, surfel_color, y, x);
       const float t1_intensity = 1 / 255.f * BSO_AT(uint8_t, surfel_color, y, x + 1);
@@ -265,7 +360,7 @@ void bso_accumulate_pose_coeffs_from_images(
                              t.depth_jacobian, H, b);
       if (use_desc) {
         add_h_b(t.r1, threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_weight(t.r1, BSO_DESC_HUBER), t.J1, H, b);
-        add_h_b(t.r2, threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_weight(t.r2, BSO_DESC_HUBER), t.J2, H, b);
+        if (!g_use_gradmag) add_h_b(t.r2, threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_weight(t.r2, BSO_DESC_HUBER), t.J2, H, b);
       }
     }
   if (visible_count) *visible_count = count;
@@ -287,7 +382,10 @@ void bso_compute_cost_and_residual_count_from_images(
                      surfel_depth, surfel_normals, surfel_color, frame_depth, frame_normals, frame_color, tex_mode, &t);
       if (!t.visible) continue;
       if (use_depth) { count += 1; sum += (double)(BSO_DEPTH_RESIDUAL_WEIGHT * bso_tukey_residual(t.raw_depth_residual, threshold_factor * BSO_DEPTH_TUKEY)); }
-      if (use_desc) {
+      if (use_desc && g_use_gradmag) {            /* BS/kernel_opt_pose.cu:1289-1297: one residual */
+        count += 1;
+        sum += (double)(threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_residual(t.r1, BSO_DESC_HUBER));
+      } else if (use_desc) {
         count += 2;
         sum += (double)(threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_residual(t.r1, BSO_DESC_HUBER));
         sum += (double)(threshold_factor * BSO_DESC_RESIDUAL_WEIGHT * bso_huber_residual(t.r2, BSO_DESC_HUBER));
@@ -321,21 +419,24 @@ void bso_build_tracking_pyramids(
   const int w = depth_camera->width, h = depth_camera->height;
   /* BadSlam::RunOdometry BS/bad_slam.cc:859-897 */
   bslam_buffer2d base_gradmag = alloc_img(base_color_uchar4->width, base_color_uchar4->height, 1);
-  bso_brightness_from_color(base_color_uchar4, &base_gradmag);
+  if (g_use_gradmag) bso_compute_sobel_gradient_magnitude(base_color_uchar4, &base_gradmag);
+  else bso_brightness_from_color(base_color_uchar4, &base_gradmag);
   out[0] = alloc_img(w, h, 4);
   out[1] = *base_normals;
   out[2] = alloc_img(w, h, 1);
   bso_calibrate_depth_and_transform_color_to_depth(depth_camera, color_camera, dp, base_depth_u16, &base_gradmag, tex_mode, &out[0], &out[2]);
   bslam_buffer2d tracked_gradmag = alloc_img(tracked_color_uchar4->width, tracked_color_uchar4->height, 1);
-  bso_brightness_from_color(tracked_color_uchar4, &tracked_gradmag);
-  /* TrackFramePairwise with use_pyramid_level_0 (BS/pairwise_frame_tracking.cc:283-291) */
+  if (g_use_gradmag) bso_compute_sobel_gradient_magnitude(tracked_color_uchar4, &tracked_gradmag);
+  else bso_brightness_from_color(tracked_color_uchar4, &tracked_gradmag);
+  /* TrackFramePairwise with use_pyramid_level_0 (BS/pairwise_frame_tracking.cc:293-301); without it the level-0 tracked images
+     stay empty placeholders (never read) and level 1 comes from CalibrateAndDownsampleImagesCUDA (:303-323) */
   out[3] = alloc_img(w, h, 4);
-  bso_calibrate_depth(dp, tracked_depth_u16, &out[3]);
   out[4] = *tracked_normals;
   out[5] = alloc_img(w, h, 1);
-  bso_set_to_read_mode_normalized(&tracked_gradmag, &out[5]);
-  free(base_gradmag.address);
-  free(tracked_gradmag.address);
+  if (g_use_pyramid_level_0) {
+    bso_calibrate_depth(dp, tracked_depth_u16, &out[3]);
+    bso_set_to_read_mode_normalized(&tracked_gradmag, &out[5]);
+  }
   for (int s = 1; s < num_scales; ++s) {   /* :312-341 */
     const int sw = (int)(w / pow(2, s)), sh = (int)(h / pow(2, s));
     bslam_buffer2d* cur = out + 6 * s;
@@ -344,9 +445,15 @@ void bso_build_tracking_pyramids(
       cur[3 * side + 0] = alloc_img(sw, sh, 4);
       cur[3 * side + 1] = alloc_img(sw, sh, 2);
       cur[3 * side + 2] = alloc_img(sw, sh, 1);
-      bso_downsample_images(&prev[3 * side + 0], &prev[3 * side + 1], &prev[3 * side + 2], tex_mode, &cur[3 * side + 0], &cur[3 * side + 1], &cur[3 * side + 2]);
+      if (side == 1 && s == 1 && !g_use_pyramid_level_0)
+        bso_calibrate_and_downsample_images(depth_camera->width == color_camera->width, dp, tracked_depth_u16, tracked_normals, &tracked_gradmag, tex_mode,
+                                            &cur[3], &cur[4], &cur[5]);
+      else
+        bso_downsample_images(&prev[3 * side + 0], &prev[3 * side + 1], &prev[3 * side + 2], tex_mode, &cur[3 * side + 0], &cur[3 * side + 1], &cur[3 * side + 2]);
     }
   }
+  free(base_gradmag.address);
+  free(tracked_gradmag.address);
 }
 
 void bso_free_tracking_pyramids(int num_scales, bslam_buffer2d* p) {
@@ -362,7 +469,7 @@ int bso_is_scale_n_pose_estimation_converged(const float x[6], float scaling_fac
   return n < scaling_factor * scaling_factor * translation_threshold;
 }
 
-/* TrackFramePairwise BS/pairwise_frame_tracking.cc:256-678 (use_pyramid_level_0 = true, use_gradmag = false) */
+/* TrackFramePairwise BS/pairwise_frame_tracking.cc:256-678 (use_pyramid_level_0 / use_gradmag: bso_set_tracking_variant) */
 void bso_track_frame_pairwise(
     int num_scales, int use_depth, int use_desc, const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* dp,
     const bslam_buffer2d* tracked_depth_u16, const bslam_buffer2d* tracked_normals, const bslam_buffer2d* tracked_color_uchar4,
@@ -373,7 +480,7 @@ void bso_track_frame_pairwise(
                               base_normals, base_color_uchar4, tex_mode, pyr);
   const int kMaxIterationsPerScale = 30;
   bslam_se3f estimate = *init1, chosen_initial = *init1;
-  for (int scale = num_scales - 1; scale >= 0; --scale) {
+  for (int scale = num_scales - 1; scale >= (g_use_pyramid_level_0 ? 0 : 1); --scale) {   /* :367 */
     const float scaling_factor = (float)pow(2, scale);
     const bslam_camera4f tcc = scaled_camera(color_camera, (depth_camera->width == color_camera->width) ? (1.f / scaling_factor) : (2.f / scaling_factor));
     const bslam_camera4f tdc = scaled_camera(depth_camera, 1.f / scaling_factor);

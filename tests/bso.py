@@ -83,6 +83,9 @@ def lib():
         "bso_compact_surfels": (None, [C.c_uint32, u32p, _BUF, _BUF]),
         "bso_track_frame_pairwise": (None, [C.c_int, C.c_int, C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, _BUF, _BUF, _BUF, C.c_int, C.c_int,
                                             P(abi.SE3f), P(abi.SE3f), P(abi.SE3f), P(C.c_int)]),
+        "bso_compute_sobel_gradient_magnitude": (None, [_BUF, _BUF]),
+        "bso_calibrate_and_downsample_images": (None, [C.c_int, _DP, _BUF, _BUF, _BUF, C.c_int, _BUF, _BUF, _BUF]),
+        "bso_set_tracking_variant": (None, [C.c_int, C.c_int]),
         "bso_build_tracking_pyramids": (None, [C.c_int, _CAM, _CAM, _DP, _BUF, _BUF, _BUF, _BUF, _BUF, _BUF, C.c_int, _BUF]),
         "bso_free_tracking_pyramids": (None, [C.c_int, _BUF]),
         "bso_accumulate_pose_coeffs_from_images": (None, [C.c_int, C.c_int, _CAM, _CAM, C.c_float, C.c_float, _BUF, _BUF, _BUF, P(abi.Mat3x4), _BUF, _BUF,

@@ -165,3 +165,134 @@ def test_pyramids_and_image_pair_kernels_match_oracle(oracle, use_desc):
         assert np.abs(H - H64).max() <= 1e-4 * np.abs(H64).max() and np.abs(b - b64).max() <= 1e-4 * np.abs(b64).max(), s
         assert abs(cost.value - cost_ref.value) <= 1e-4 * abs(cost_ref.value), s
     O.bso_free_tracking_pyramids(num_scales, pyr)
+
+
+def test_sobel_and_calibrate_downsample_bit_exact(oracle):
+    """ComputeSobelGradientMagnitudeCUDA (BS/kernel_pairwise_frame_tracking... via kernels_odometry: 3x3 Sobel of the luma, u8) and
+    CalibrateAndDownsampleImagesCUDA (raw u16 depth -> calibrated, median-selected half-resolution depth + normals + colour) are
+    integer / selection work: every output byte equals the oracle's."""
+    import torch
+    scene, base, tracked, truth = two_views(True, seed=23)
+    O, L = bso.lib(), badslam_amd.lib()
+    ctx = badslam_amd.Context(0)
+    ctx.set_texture_mode(scene.tex_mode)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h, w = tracked.depth.shape
+    # --- Sobel
+    ref_gm = np.zeros((h, w), np.uint8)
+    tv = tracked.view()
+    O.bso_compute_sobel_gradient_magnitude(C.byref(tv.color), C.byref(bso.np_buffer2d(ref_gm)))
+    t_col = dev_img(torch, tracked.color)
+    gm = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    x, y = abi.Buffer2D(t_col.data_ptr(), h, w, w * 4), buf(gm)
+    badslam_amd.check(L.bslam_compute_sobel_gradient_magnitude(ctx.handle, stream, C.byref(x), C.byref(y)))
+    torch.cuda.synchronize()
+    assert np.array_equal(gm.cpu().numpy(), ref_gm) and ref_gm.max() >= 8 and (ref_gm > 0).mean() > 0.2
+    # --- calibrate + downsample, with and without halving the colour image
+    dp = scene.depth_params()
+    cf = dev_img(torch, scene.cfactor)
+    dp_dev = scene.depth_params(buf(cf))
+    t_d16 = dev_img(torch, tracked.depth.view(np.int16))
+    t_n = dev_img(torch, tracked.normals.view(np.int16))
+    for downsample_color in (1, 0):
+        ch, cw = (h // 2, w // 2) if downsample_color else (h, w)
+        src_c = ref_gm if downsample_color else np.ascontiguousarray(ref_gm[:h // 2, :w // 2])
+        rd, rn, rc = np.zeros((h // 2, w // 2), np.float32), np.zeros((h // 2, w // 2), np.uint16), np.zeros((h // 2, w // 2), np.uint8)
+        O.bso_calibrate_and_downsample_images(downsample_color, C.byref(dp), C.byref(tv.depth), C.byref(tv.normals), C.byref(bso.np_buffer2d(src_c)),
+                                              scene.tex_mode, C.byref(bso.np_buffer2d(rd)), C.byref(bso.np_buffer2d(rn)), C.byref(bso.np_buffer2d(rc)))
+        d = torch.zeros((h // 2, w // 2), dtype=torch.float32, device="cuda")
+        n = torch.zeros((h // 2, w // 2), dtype=torch.int16, device="cuda")
+        c = torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda")
+        sc = dev_img(torch, src_c)
+        i1, i2, i3, o1, o2, o3 = buf(t_d16), buf(t_n), buf(sc), buf(d), buf(n), buf(c)
+        badslam_amd.check(L.bslam_calibrate_and_downsample_images(ctx.handle, stream, downsample_color, C.byref(dp_dev), C.byref(i1), C.byref(i2), C.byref(i3),
+                                                                 C.byref(o1), C.byref(o2), C.byref(o3)))
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), rd.view(np.uint32)), downsample_color
+        valid = rd > 0
+        assert valid.mean() > 0.5
+        assert np.array_equal(n.cpu().numpy().view(np.uint16)[valid], rn[valid]), downsample_color
+        assert np.array_equal(c.cpu().numpy(), rc), downsample_color
+
+
+def test_gradmag_image_pair_kernels_match_oracle(oracle):
+    """The use_gradmag forms of the two image-pair kernels (one colour residual on the gradient-magnitude images,
+    BS/kernel_opt_pose.cu:713-937 and 1173-1338) on the oracle's own pyramids, every scale."""
+    import torch
+    scene, base, tracked, truth = two_views(True, seed=17)
+    O, L = bso.lib(), badslam_amd.lib()
+    ctx = badslam_amd.Context(0)
+    ctx.set_texture_mode(scene.tex_mode)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    num_scales = 3
+    dp = scene.depth_params()
+    tv, bv = tracked.view(), base.view()
+    pyr = (abi.Buffer2D * (6 * num_scales))()
+    O.bso_set_tracking_variant(1, 1)
+    try:
+        O.bso_build_tracking_pyramids(num_scales, C.byref(scene.color_camera), C.byref(scene.depth_camera), C.byref(dp), C.byref(tv.depth), C.byref(tv.normals),
+                                      C.byref(tv.color), C.byref(bv.depth), C.byref(bv.normals), C.byref(bv.color), scene.tex_mode, pyr)
+
+        def as_np(b, dtype):
+            n = b.height * b.pitch // np.dtype(dtype).itemsize
+            return np.ctypeslib.as_array(C.cast(b.address, P(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).reshape(b.height, -1)[:, :b.width].copy()
+
+        pose = bso.se3_mul(truth, bso.se3_exp(np.array([0.002, -0.001, 0.0015, 0.0005, -0.0004, 0.0006], np.float32)))
+        M = bso.se3_matrix3x4(bso.se3_inverse(pose))
+        for s in range(num_scales):
+            f = 1.0 / 2 ** s
+            sc = lambda c: bso.make_camera(c.fx * f, c.fy * f, c.cx * f, c.cy * f, int(f * c.width + 0.5), int(f * c.height + 0.5))
+            tcc, tdc = sc(scene.color_camera), sc(scene.depth_camera)
+            Pp = pyr[6 * s:6 * s + 6]
+            H64, b64 = np.zeros(21), np.zeros(6)
+            vis = C.c_uint32()
+            O.bso_accumulate_pose_coeffs_from_images(1, 1, C.byref(tcc), C.byref(tdc), scene.baseline_fx, float(2 ** s), C.byref(Pp[3]), C.byref(Pp[4]),
+                                                     C.byref(Pp[5]), C.byref(M), C.byref(Pp[0]), C.byref(Pp[1]), C.byref(Pp[2]), scene.tex_mode,
+                                                     H64.ctypes.data_as(P(C.c_double)), b64.ctypes.data_as(P(C.c_double)), C.byref(vis))
+            cnt_ref, cost_ref = C.c_uint32(), C.c_double()
+            O.bso_compute_cost_and_residual_count_from_images(1, 1, C.byref(tcc), C.byref(tdc), scene.baseline_fx, float(2 ** s), C.byref(Pp[3]),
+                                                              C.byref(Pp[4]), C.byref(Pp[5]), C.byref(M), C.byref(Pp[0]), C.byref(Pp[1]), C.byref(Pp[2]),
+                                                              scene.tex_mode, C.byref(cnt_ref), C.byref(cost_ref))
+            dtypes = [np.float32, np.uint16, np.uint8, np.float32, np.uint16, np.uint8]
+            T = [dev_img(torch, as_np(Pp[i], dt).view(np.int16 if dt == np.uint16 else dt)) for i, dt in enumerate(dtypes)]
+            D = [buf(t) for t in T]
+            H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+            v = C.c_uint32()
+            badslam_amd.check(L.bslam_accumulate_pose_coeffs_from_images_gradmag(
+                ctx.handle, stream, 1, 1, C.byref(tcc), C.byref(tdc), scene.baseline_fx, float(2 ** s), C.byref(D[3]), C.byref(D[4]), C.byref(D[5]), C.byref(M),
+                C.byref(D[0]), C.byref(D[1]), C.byref(D[2]), C.byref(v), H.ctypes.data_as(P(C.c_float)), b.ctypes.data_as(P(C.c_float))))
+            cnt, cost = C.c_uint32(), C.c_float()
+            badslam_amd.check(L.bslam_compute_cost_and_residual_count_from_images_gradmag(
+                ctx.handle, stream, 1, 1, C.byref(tcc), C.byref(tdc), scene.baseline_fx, float(2 ** s), C.byref(D[3]), C.byref(D[4]), C.byref(D[5]), C.byref(M),
+                C.byref(D[0]), C.byref(D[1]), C.byref(D[2]), C.byref(cnt), C.byref(cost)))
+            assert v.value == vis.value and cnt.value == cnt_ref.value and vis.value > 500, (s, v.value, vis.value, cnt.value, cnt_ref.value)
+            assert np.abs(H - H64).max() <= 1e-4 * np.abs(H64).max() and np.abs(b - b64).max() <= 1e-4 * np.abs(b64).max(), s
+            assert abs(cost.value - cost_ref.value) <= 1e-4 * abs(cost_ref.value), s
+            # and it is a different problem from the two-residual descriptor form
+            H2, b2 = np.zeros(21, np.float32), np.zeros(6, np.float32)
+            badslam_amd.check(L.bslam_accumulate_pose_coeffs_from_images(
+                ctx.handle, stream, 1, 1, C.byref(tcc), C.byref(tdc), scene.baseline_fx, float(2 ** s), C.byref(D[3]), C.byref(D[4]), C.byref(D[5]), C.byref(M),
+                C.byref(D[0]), C.byref(D[1]), C.byref(D[2]), C.byref(v), H2.ctypes.data_as(P(C.c_float)), b2.ctypes.data_as(P(C.c_float))))
+            assert np.abs(H2 - H).max() > 1e-3 * np.abs(H).max()
+        O.bso_free_tracking_pyramids(num_scales, pyr)
+    finally:
+        O.bso_set_tracking_variant(0, 1)
+
+
+@pytest.mark.parametrize("use_gradmag,use_pyramid_level_0", [(True, True), (False, False), (True, False)])
+def test_tracker_variants_match_oracle(oracle, use_gradmag, use_pyramid_level_0):
+    """TrackFramePairwise's two switches (BS/pairwise_frame_tracking.cc:164-166, 283-341, 367) against the oracle's loop."""
+    scene, base, tracked, truth = two_views(True)
+    ba = make_ba(scene)
+    est, its = ba.TrackKeyframePair(1, 0, bso.se3_identity(), num_scales=4, use_pyramid_level_0=use_pyramid_level_0, use_gradmag=use_gradmag)
+    err = np.abs(bso.se3_log(bso.se3_mul(bso.se3_inverse(est), truth))).max()
+    assert err < 3e-4, (err, its)
+    bso.lib().bso_set_tracking_variant(int(use_gradmag), int(use_pyramid_level_0))
+    try:
+        ref, ref_its = scene.track_frame_pairwise(tracked, base, bso.se3_identity(), num_scales=4)
+    finally:
+        bso.lib().bso_set_tracking_variant(0, 1)
+    assert np.abs(bso.se3_to_np(est) - bso.se3_to_np(ref)).max() < 2e-5, (bso.se3_to_np(est), bso.se3_to_np(ref))
+    assert all(abs(a - b) <= 1 for a, b in zip(its, ref_its)), (its, ref_its)
+    if not use_pyramid_level_0:
+        assert its[0] == 0 and its[1] > 0
