@@ -552,6 +552,9 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
 #ifndef BSLAM_GEOM_DESC_WAVES
 #define BSLAM_GEOM_DESC_WAVES 4
 #endif
+#ifndef BSLAM_GEOM_SPECULATE
+#define BSLAM_GEOM_SPECULATE 1
+#endif
 template <int R, int kPass, bool kDepth>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_DESC_WAVES))) void geometry_desc_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
                                                                  Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
@@ -585,7 +588,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
-      if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      DescSamples ds;
+      bool has_desc = false;
+      if constexpr (kPass == 1 && BSLAM_GEOM_SPECULATE != 0) {
+        // the three quad gathers of the descriptor samples do not depend on the pixel record: issued with the record gather,
+        // before the association test (see pose_accumulate_kernel)
+        if (!on[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        const uint2 rec = load_record(c, kf, p);
+        f2 color_pxy, t1, t2;
+        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+        ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+        asm volatile("" ::: "memory");
+        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+      } else {
+        if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      }
       if constexpr (kPass == 0) {
         const f3 ln = u16_to_image_space_normal(p.pixel_normal);
         a[r][0] += rot_row(Rm[0], Rm[1], Rm[2], ln);
@@ -604,12 +622,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
           a[r][0] += w * dj * dj;
           a[r][5] += w * raw * dj;
         }
-        f2 color_pxy;
-        if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
-          f2 t1, t2;
-          project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+        if constexpr (BSLAM_GEOM_SPECULATE == 0) {
+          f2 color_pxy;
+          has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+          if (has_desc) {
+            f2 t1, t2;
+            project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+            ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+          }
+        }
+        if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+          descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           const float jp1 = descriptor_position_jacobian(gx1, gy1, c.cfx, c.cfy, rn, p.local);
           const float jp2 = descriptor_position_jacobian(gx2, gy2, c.cfx, c.cfy, rn, p.local);
           const float jd = -1.f;

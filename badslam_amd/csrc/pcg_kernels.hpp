@@ -99,11 +99,16 @@ struct DescTerms {
   float gx1, gy1, gx2, gy2;   // image gradients already multiplied by the colour focal lengths
 };
 
-__device__ __forceinline__ DescTerms descriptor_terms(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, float radius_squared, float d1, float d2, f2 color_pxy) {
-  DescTerms t;
+// In two steps around the association test: the sample positions depend on the surfel and the pose only, so their three quad
+// gathers are issued together with the record gather (see pose_accumulate_kernel); the filters run after the test.
+__device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, float radius_squared, f2 color_pxy) {
   f2 t1, t2;
   tangent_projections(gp, gn, radius_squared, kf.frame_T_global, c, &t1, &t2);
-  descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1, d2, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
+  return descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+}
+__device__ __forceinline__ DescTerms descriptor_terms_finish(const CamConsts& c, const KfDev& kf, const DescSamples& ds, float d1, float d2) {
+  DescTerms t;
+  descriptor_samples_finish(kf, c, ds, d1, d2, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
   t.gx1 *= c.cfx; t.gx2 *= c.cfx;
   t.gy1 *= c.cfy; t.gy2 *= c.cfy;
   t.w1 = desc_weight(t.r1);
@@ -157,7 +162,19 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 #pragma unroll
     for (int r = 0; r < kPcgR; ++r) {
       Proj p;
-      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      DescSamples ds;
+      bool has_desc = false;
+      if constexpr (kDesc) {
+        if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        const uint2 rec = load_record(c, kf, p);
+        f2 color_pxy;
+        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        ds = descriptor_terms_issue(c, kf, gp[r], gn[r], r2[r], color_pxy);
+        asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
+        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+      } else {
+        if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      }
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
@@ -199,10 +216,9 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         }
       }
       if (kDesc) {                                               // :330-511
-        f2 color_pxy;
-        visible = visible && depth_to_color_pxy(c, p.pxy, &color_pxy);
+        visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms(c, kf, gp[r], gn[r], r2[r], d1[r], d2[r], color_pxy);
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, d1[r], d2[r]);
         const f3 ls = p.local;
         if (P.optimize_geometry) {                               // :364-399
           const float jp1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);   // gx, gy already carry fx, fy
@@ -412,7 +428,19 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
 #pragma unroll
     for (int r = 0; r < kPcgR; ++r) {
       Proj p;
-      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      DescSamples ds;
+      bool has_desc = false;
+      if constexpr (kDesc) {
+        if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        const uint2 rec = load_record(c, kf, p);
+        f2 color_pxy;
+        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        ds = descriptor_terms_issue(c, kf, gp[r], gn[r], r2[r], color_pxy);
+        asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
+        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+      } else {
+        if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      }
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
@@ -456,10 +484,9 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         }
       }
       if (kDesc) {
-        f2 color_pxy;
-        visible = visible && depth_to_color_pxy(c, p.pxy, &color_pxy);
+        visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms(c, kf, gp[r], gn[r], r2[r], d1[r], d2[r], color_pxy);
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, d1[r], d2[r]);
         const f3 ls = p.local;
         float sum_1 = 0, sum_2 = 0, gj1 = 0, gj2 = 0;
         float J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};

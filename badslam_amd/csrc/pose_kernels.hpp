@@ -35,6 +35,9 @@ constexpr int kPoseThreads = 256;
 #ifndef BSLAM_POSE_PREFETCH
 #define BSLAM_POSE_PREFETCH 0
 #endif
+#ifndef BSLAM_POSE_SPECULATE
+#define BSLAM_POSE_SPECULATE 1
+#endif
 constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
 constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
 constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
@@ -139,6 +142,27 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
       Proj p;
 #if BSLAM_POSE_PREFETCH
       if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p) || !associate_with_record(c, kf, gn[r], pre[r], &p)) continue;
+#elif BSLAM_POSE_SPECULATE
+      // The descriptor samples depend on the surfel and the pose only, not on the pixel record: their three quad gathers are
+      // issued together with the record gather, BEFORE the association test (99.6 % of the in-bounds pairs pass it), so a
+      // pair waits for one L2 round trip instead of two and the depth residual is evaluated while the quads are in flight.
+      DescSamples ds;
+      bool has_desc = false;
+      if constexpr (!kDesc) {
+        if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      } else {
+        if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        const uint2 rec = load_record(c, kf, p);
+        f2 color_pxy;
+        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        // unconditional (no join in front of the record's wait, so it can be s_waitcnt vmcnt(3)): the quad table's clamp
+        // addressing makes every address valid, whatever the sample position
+        f2 t1, t2;
+        project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+        ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+        asm volatile("" ::: "memory");   // keeps the compiler from sinking the gathers below the branches that follow
+        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+      }
 #else
       if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
 #endif
@@ -151,12 +175,18 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
         count += 1;
       }
       if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
+#if BSLAM_POSE_SPECULATE
+        if (has_desc) {
+          float r1, rr2, gx1, gy1, gx2, gy2;
+          descriptor_samples_finish(kf, c, ds, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+#else
         f2 color_pxy;
         if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
           f2 t1, t2;
           project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
           float r1, rr2, gx1, gy1, gx2, gy2;
           descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+#endif
           gx1 *= c.cfx; gx2 *= c.cfx;
           gy1 *= c.cfy; gy2 *= c.cfy;
           descriptor_pose_jacobian(gx1, gy1, p.local, J);
