@@ -536,7 +536,7 @@ int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float*
 }
 
 int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch) {
-  if (!ctx || keyframes_per_launch < 0) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad argument");
+  if (!ctx || keyframes_per_launch < -1) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad argument");
   ctx->geom_kf_chunk = keyframes_per_launch;
   return BSLAM_OK;
 }
@@ -883,6 +883,14 @@ int bslam_update_surfel_normals(
   return BSLAM_OK;
 }
 
+// Launches of (nearly) equal length instead of full chunks and a short tail: ceil(K / chunk) launches of ceil(K / launches)
+// keyframes.  0 stays 0 (one launch for the whole list).
+static int equal_keyframe_chunks(int keyframe_count, int chunk) {
+  if (chunk <= 0 || keyframe_count <= chunk) return chunk;
+  const int launches = (keyframe_count + chunk - 1) / chunk;
+  return (keyframe_count + launches - 1) / launches;
+}
+
 int bslam_optimize_geometry_iteration(
     bslam_context* ctx, void* stream_, int use_depth_residuals, int use_descriptor_residuals,
     const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera, const bslam_depth_params* depth_params,
@@ -916,7 +924,7 @@ int bslam_optimize_geometry_iteration(
 #endif
     const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU) / 8u);   // slots per XCD and launch
     // keyframes per launch (bslam_set_geometry_keyframe_chunk; default 128: K = 200: geometry kernel 6.9 -> 5.5 ms)
-    const int kf_chunk = ctx->geom_kf_chunk;
+    const int kf_chunk = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 128 : ctx->geom_kf_chunk);
     float* acc = nullptr;
     uint32_t acc_pitch = 0;
     if (kf_chunk > 0 && keyframe_count > kf_chunk) {
@@ -948,8 +956,12 @@ int bslam_optimize_geometry_iteration(
 #ifndef BSLAM_GEOM_WG_PER_CU_DESC
 #define BSLAM_GEOM_WG_PER_CU_DESC 4
 #endif
-    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU_DESC) / 8u);   // slots per XCD and launch
-    const int kf_chunk = ctx->geom_kf_chunk > 0 ? ctx->geom_kf_chunk : keyframe_count;
+    const uint32_t resident = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU_DESC) / 8u);   // slots per XCD that fit at once
+    const uint32_t launches = (sc.slots_per_xcd + resident - 1) / resident;
+    const uint32_t per_launch = std::max<uint32_t>(1u, (sc.slots_per_xcd + launches - 1) / std::max(1u, launches));     // equal shares
+    // keyframes per launch: default 64 (K = 300: 26.7 ms per iteration with 128, 24.6 with 64, 25.3 with 32)
+    const int kf_chunk_set = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 64 : ctx->geom_kf_chunk);
+    const int kf_chunk = kf_chunk_set > 0 ? kf_chunk_set : keyframe_count;
     float* acc = nullptr;
     uint32_t acc_pitch = 0;
     if (keyframe_count > kf_chunk) {

@@ -63,7 +63,22 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
 #pragma unroll
     for (int r = 0; r < kIntrR; ++r) {
       Proj p;
-      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      DescSamples ds;
+      bool has_desc = false;
+      if constexpr (kColorIntr) {
+        // the quad gathers of the descriptor samples are issued with the record gather, before the association test
+        // (see pose_accumulate_kernel)
+        if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        const uint2 rec = load_record(c, kf, p);
+        f2 color_pxy, t1, t2;
+        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
+        ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+        asm volatile("" ::: "memory");
+        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+      } else {
+        if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+      }
       const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
       if (kDepthIntr) {                                           // BS/kernel_opt_intrinsics.cu:82-118, 170-196
         const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
@@ -96,12 +111,9 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         }
       }
       if (kColorIntr) {                                           // :120-158, 198-216
-        f2 color_pxy;
-        if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
-          f2 t1, t2;
-          tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
+        if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+          descriptor_samples_finish(kf, c, ds, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           float j1[4], j2[4];
           color_intrinsics_jacobian(gx1, gy1, nx, ny, j1);
           color_intrinsics_jacobian(gx2, gy2, nx, ny, j2);

@@ -26,6 +26,12 @@ constexpr int kPcgThreads = 256;
 #ifndef BSLAM_PCG_R
 #define BSLAM_PCG_R 2
 #endif
+// ---------------------------------------------------------------------------------------------
+// PCGStep1 for all keyframes (BS/kernel_pcg.cu:645-1025)
+// ---------------------------------------------------------------------------------------------
+#ifndef BSLAM_PCG_STEP1_WAVES_DESC
+#define BSLAM_PCG_STEP1_WAVES_DESC 3
+#endif
 constexpr int kPcgR = BSLAM_PCG_R;
 constexpr int kPcgTile = kPcgThreads * kPcgR;
 constexpr int kPcgPoseRow = 12;    // init: r[6], M[6];  step1: g[6] (+6 unused)
@@ -101,11 +107,18 @@ struct DescTerms {
 
 // In two steps around the association test: the sample positions depend on the surfel and the pose only, so their three quad
 // gathers are issued together with the record gather (see pose_accumulate_kernel); the filters run after the test.
-__device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c, const KfDev& kf, f3 gp, f3 gn, float radius_squared, f2 color_pxy) {
+__device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c, const KfDev& kf, f3 tp1, f3 tp2, f2 color_pxy) {
   f2 t1, t2;
-  tangent_projections(gp, gn, radius_squared, kf.frame_T_global, c, &t1, &t2);
+  project_tangent_points(tp1, tp2, kf.frame_T_global, c, &t1, &t2);
   return descriptor_samples_issue(kf, c, color_pxy, t1, t2);
 }
+
+// Photometric variants: per-surfel constants that a pair only reads (normal, the two tangent sample points, descriptors, and
+// in step 1 the surfel's entries of p) live in LDS -- [component][thread], conflict-free, private to the thread, no barrier --
+// instead of VGPRs: registers for one more wave per SIMD, and the tangent points are formed once per surfel instead of once
+// per pair.
+constexpr int kPcgStateComps = 14;   // 0-2 normal, 3-5 / 6-8 tangent points, 9-10 descriptor, 11-13 p entries (step 1)
+#define BSLAM_PCG_ST(r, comp) state[((r) * kPcgStateComps + (comp)) * kPcgThreads + threadIdx.x]
 __device__ __forceinline__ DescTerms descriptor_terms_finish(const CamConsts& c, const KfDev& kf, const DescSamples& ds, float d1, float d2) {
   DescTerms t;
   descriptor_samples_finish(kf, c, ds, d1, d2, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
@@ -127,13 +140,13 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float red[2][4][32];
+  __shared__ float red[2][4][16];
   __shared__ float redg[4][32];
 
   f3 gp[kPcgR], gn[kPcgR];
   bool valid[kPcgR];
   uint32_t idx[kPcgR];
-  float r2[kPcgR], d1[kPcgR], d2[kPcgR];
+  __shared__ float state[kDesc ? kPcgStateComps * kPcgR * kPcgThreads : 1];
   float ar[kPcgR][3], aM[kPcgR][3];
 #pragma unroll
   for (int r = 0; r < kPcgR; ++r) {
@@ -142,7 +155,14 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
     gn[r] = unpack_normal(s.normal[idx[r]]);
-    if (kDesc) { r2[r] = s.radius_squared[idx[r]]; d1[r] = s.d1[idx[r]]; d2[r] = s.d2[idx[r]]; }
+    if constexpr (kDesc) {
+      f3 tp1, tp2;
+      tangent_points(gp[r], gn[r], s.radius_squared[idx[r]], &tp1, &tp2);
+      BSLAM_PCG_ST(r, 0) = gn[r].x; BSLAM_PCG_ST(r, 1) = gn[r].y; BSLAM_PCG_ST(r, 2) = gn[r].z;
+      BSLAM_PCG_ST(r, 3) = tp1.x; BSLAM_PCG_ST(r, 4) = tp1.y; BSLAM_PCG_ST(r, 5) = tp1.z;
+      BSLAM_PCG_ST(r, 6) = tp2.x; BSLAM_PCG_ST(r, 7) = tp2.y; BSLAM_PCG_ST(r, 8) = tp2.z;
+      BSLAM_PCG_ST(r, 9) = s.d1[idx[r]]; BSLAM_PCG_ST(r, 10) = s.d2[idx[r]];
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { ar[r][j] = 0.f; aM[r][j] = 0.f; }
   }
@@ -169,9 +189,10 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         const uint2 rec = load_record(c, kf, p);
         f2 color_pxy;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
-        ds = descriptor_terms_issue(c, kf, gp[r], gn[r], r2[r], color_pxy);
+        ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),
+                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy);
         asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
-        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+        if (!associate_with_record(c, kf, mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)), rec, &p)) continue;
       } else {
         if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       }
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
           }
         }
         if (kIntr && P.optimize_depth_intr) {                    // :258-322
-          const DepthIntrinsicsTerms t = depth_intrinsics_terms(c, kf, p, gn[r], inv_stddev, P.depth_intr_start);
+          const DepthIntrinsicsTerms t = depth_intrinsics_terms(c, kf, p, kDesc ? mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)) : gn[r], inv_stddev, P.depth_intr_start);
           if (t.valid) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       if (kDesc) {                                               // :330-511
         visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms_finish(c, kf, ds, d1[r], d2[r]);
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10));
         const f3 ls = p.local;
         if (P.optimize_geometry) {                               // :364-399
           const float jp1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);   // gx, gy already carry fx, fy
@@ -369,12 +390,6 @@ __global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// PCGStep1 for all keyframes (BS/kernel_pcg.cu:645-1025)
-// ---------------------------------------------------------------------------------------------
-#ifndef BSLAM_PCG_STEP1_WAVES_DESC
-#define BSLAM_PCG_STEP1_WAVES_DESC 3
-#endif
 template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_PCG_STEP1_WAVES_DESC : 4))) void pcg_step1_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
@@ -383,13 +398,13 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float red[2][4][32];
+  __shared__ float red[2][4][16];
   __shared__ float redg[4][32];
 
   f3 gp[kPcgR], gn[kPcgR];
   bool valid[kPcgR];
   uint32_t idx[kPcgR];
-  float r2[kPcgR], d1[kPcgR], d2[kPcgR];
+  __shared__ float state[kDesc ? kPcgStateComps * kPcgR * kPcgThreads : 1];
   float ps[kPcgR][3], ag[kPcgR][3];
 #pragma unroll
   for (int r = 0; r < kPcgR; ++r) {
@@ -398,13 +413,21 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
     gn[r] = unpack_normal(s.normal[idx[r]]);
-    if (kDesc) { r2[r] = s.radius_squared[idx[r]]; d1[r] = s.d1[idx[r]]; d2[r] = s.d2[idx[r]]; }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { ps[r][j] = 0.f; ag[r][j] = 0.f; }
     if (P.optimize_geometry) {
       const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
       ps[r][0] = P.p[base];
       if (kDesc) { ps[r][1] = P.p[base + 1]; ps[r][2] = P.p[base + 2]; }
+    }
+    if constexpr (kDesc) {
+      f3 tp1, tp2;
+      tangent_points(gp[r], gn[r], s.radius_squared[idx[r]], &tp1, &tp2);
+      BSLAM_PCG_ST(r, 0) = gn[r].x; BSLAM_PCG_ST(r, 1) = gn[r].y; BSLAM_PCG_ST(r, 2) = gn[r].z;
+      BSLAM_PCG_ST(r, 3) = tp1.x; BSLAM_PCG_ST(r, 4) = tp1.y; BSLAM_PCG_ST(r, 5) = tp1.z;
+      BSLAM_PCG_ST(r, 6) = tp2.x; BSLAM_PCG_ST(r, 7) = tp2.y; BSLAM_PCG_ST(r, 8) = tp2.z;
+      BSLAM_PCG_ST(r, 9) = s.d1[idx[r]]; BSLAM_PCG_ST(r, 10) = s.d2[idx[r]];
+      BSLAM_PCG_ST(r, 11) = ps[r][0]; BSLAM_PCG_ST(r, 12) = ps[r][1]; BSLAM_PCG_ST(r, 13) = ps[r][2];
     }
   }
   float glob[kPcgGlobRow];
@@ -435,9 +458,10 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         const uint2 rec = load_record(c, kf, p);
         f2 color_pxy;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
-        ds = descriptor_terms_issue(c, kf, gp[r], gn[r], r2[r], color_pxy);
+        ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),
+                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy);
         asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
-        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+        if (!associate_with_record(c, kf, mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)), rec, &p)) continue;
       } else {
         if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       }
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         float sum = 0;
         float gj = 0;
         float J[6] = {0, 0, 0, 0, 0, 0};
-        if (P.optimize_geometry) { gj = depth_position_jacobian(inv_stddev); sum += gj * ps[r][0]; }
+        if (P.optimize_geometry) { gj = depth_position_jacobian(inv_stddev); sum += gj * (kDesc ? BSLAM_PCG_ST(r, 11) : ps[r][0]); }
         if (opt_pose) {
           depth_pose_jacobian(inv_stddev, rn, lu, J);
 #pragma unroll
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         DepthIntrinsicsTerms t;
         t.valid = false;
         if (kIntr && P.optimize_depth_intr) {
-          t = depth_intrinsics_terms(c, kf, p, gn[r], inv_stddev, P.depth_intr_start);
+          t = depth_intrinsics_terms(c, kf, p, kDesc ? mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)) : gn[r], inv_stddev, P.depth_intr_start);
           if (t.valid) {
             sum += t.d[2] * pdi[2];
             sum += t.d[3] * pdi[3];
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       if (kDesc) {
         visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms_finish(c, kf, ds, d1[r], d2[r]);
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10));
         const f3 ls = p.local;
         float sum_1 = 0, sum_2 = 0, gj1 = 0, gj2 = 0;
         float J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};
@@ -494,10 +518,11 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         if (P.optimize_geometry) {
           gj1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);
           gj2 = descriptor_position_jacobian(t.gx2, t.gy2, 1.f, 1.f, rn, ls);
-          sum_1 += gj1 * ps[r][0];
-          sum_2 += gj2 * ps[r][0];
-          sum_1 += -1.f * ps[r][1];
-          sum_2 += -1.f * ps[r][2];
+          const float ps0 = BSLAM_PCG_ST(r, 11);
+          sum_1 += gj1 * ps0;
+          sum_2 += gj2 * ps0;
+          sum_1 += -1.f * BSLAM_PCG_ST(r, 12);
+          sum_2 += -1.f * BSLAM_PCG_ST(r, 13);
         }
         if (opt_pose) {
           descriptor_pose_jacobian(t.gx1, t.gy1, ls, J1);

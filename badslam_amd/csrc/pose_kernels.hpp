@@ -32,12 +32,6 @@ constexpr int kPoseThreads = 256;
 #ifndef BSLAM_POSE_R_DESC
 #define BSLAM_POSE_R_DESC 2
 #endif
-#ifndef BSLAM_POSE_PREFETCH
-#define BSLAM_POSE_PREFETCH 0
-#endif
-#ifndef BSLAM_POSE_SPECULATE
-#define BSLAM_POSE_SPECULATE 1
-#endif
 constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
 constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
 constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
@@ -79,12 +73,12 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 
 // Occupancy target handed to the register allocator: without it the 32 accumulators' zero initialisation lands in a
 // second 32-register tuple (104 VGPRs, 4 waves per SIMD); with it the geometric kernel fits 76 VGPRs (6 waves).
-// The photometric variants need ~122 VGPRs (4 waves).
+// The photometric variants fit 95 VGPRs (5 waves) with their per-surfel constants in LDS.
 #ifndef BSLAM_POSE_WAVES_GEO
 #define BSLAM_POSE_WAVES_GEO 6
 #endif
 #ifndef BSLAM_POSE_WAVES_DESC
-#define BSLAM_POSE_WAVES_DESC 4
+#define BSLAM_POSE_WAVES_DESC 5
 #endif
 #define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : BSLAM_POSE_WAVES_GEO)))
 template <bool kDepth, bool kDesc, int kPoseR>
@@ -106,8 +100,12 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
   bool valid[kPoseR];
-  float d1[kPoseR], d2[kPoseR];
-  f3 tp1[kPoseR], tp2[kPoseR];   // tangent sample points of the descriptor residual (per surfel, not per pair)
+  // Photometric variant: the 14 per-surfel constants (position, normal, the two tangent sample points of the descriptor
+  // residual, the descriptor) live in LDS -- [component][thread]: conflict-free, private to the thread, no barrier -- instead
+  // of 28 VGPRs, and are read back where a pair needs them: 123 -> 95 VGPRs, one more wave per SIMD (518 -> 495 us at K = 50).
+  constexpr int kState = 14;
+  __shared__ float state[kDesc ? kState * kPoseR * kPoseThreads : 1];
+  auto st = [&](int r, int comp) -> float& { return state[(r * kState + comp) * kPoseThreads + threadIdx.x]; };
 #pragma unroll
   for (int r = 0; r < kPoseR; ++r) {
     const uint32_t i = surfel_of_slot(sc, slot, r, kPoseR);
@@ -115,7 +113,15 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     const uint32_t j = valid[r] ? i : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
-    if (kDesc) { d1[r] = s.d1[j]; d2[r] = s.d2[j]; tangent_points(gp[r], gn[r], s.radius_squared[j], &tp1[r], &tp2[r]); }
+    if constexpr (kDesc) {
+      f3 tp1, tp2;
+      tangent_points(gp[r], gn[r], s.radius_squared[j], &tp1, &tp2);
+      st(r, 0) = gp[r].x; st(r, 1) = gp[r].y; st(r, 2) = gp[r].z;
+      st(r, 3) = gn[r].x; st(r, 4) = gn[r].y; st(r, 5) = gn[r].z;
+      st(r, 6) = tp1.x; st(r, 7) = tp1.y; st(r, 8) = tp1.z;
+      st(r, 9) = tp2.x; st(r, 10) = tp2.y; st(r, 11) = tp2.z;
+      st(r, 12) = s.d1[j]; st(r, 13) = s.d2[j];
+    }
   }
 
   for (int k = kf_begin; k < kf_end; ++k) {
@@ -126,46 +132,29 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
     uint32_t count = 0;
 
-#if BSLAM_POSE_PREFETCH
-    // The record gathers of all kPoseR surfels are issued up front (the cheap projection is simply evaluated twice), so that
-    // only the first one's latency is exposed: the others arrive while the earlier surfels are being processed.
-    uint2 pre[kPoseR];
-#pragma unroll
-    for (int r = 0; r < kPoseR; ++r) {
-      Proj q;
-      pre[r] = make_uint2(0u, (uint32_t)BSLAM_INVALID_DEPTH_BIT << 16);
-      if (valid[r] && project_to_pixel(c, kf, gp[r], &q)) pre[r] = load_record(c, kf, q);
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < kPoseR; ++r) {
       Proj p;
-#if BSLAM_POSE_PREFETCH
-      if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p) || !associate_with_record(c, kf, gn[r], pre[r], &p)) continue;
-#elif BSLAM_POSE_SPECULATE
-      // The descriptor samples depend on the surfel and the pose only, not on the pixel record: their three quad gathers are
-      // issued together with the record gather, BEFORE the association test (99.6 % of the in-bounds pairs pass it), so a
-      // pair waits for one L2 round trip instead of two and the depth residual is evaluated while the quads are in flight.
       DescSamples ds;
       bool has_desc = false;
+      if (!valid[r]) continue;
       if constexpr (!kDesc) {
-        if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
+        if (!project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       } else {
-        if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
+        // The descriptor samples depend on the surfel and the pose only, not on the pixel record: their three quad gathers
+        // are issued together with the record gather, BEFORE the association test (99.6 % of the in-bounds pairs pass it),
+        // so a pair waits for one L2 round trip instead of two and the depth residual is evaluated while the quads are in
+        // flight (551 -> 517 us at K = 50).  Issued unconditionally -- the quad table's clamp addressing makes every address
+        // valid -- so that no control-flow join sits in front of the record's wait (s_waitcnt vmcnt(3), not vmcnt(0)).
+        if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) continue;
         const uint2 rec = load_record(c, kf, p);
-        f2 color_pxy;
+        f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
-        // unconditional (no join in front of the record's wait, so it can be s_waitcnt vmcnt(3)): the quad table's clamp
-        // addressing makes every address valid, whatever the sample position
-        f2 t1, t2;
-        project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
+        project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
         ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
         asm volatile("" ::: "memory");   // keeps the compiler from sinking the gathers below the branches that follow
-        if (!associate_with_record(c, kf, gn[r], rec, &p)) continue;
+        if (!associate_with_record(c, kf, mk3(st(r, 3), st(r, 4), st(r, 5)), rec, &p)) continue;
       }
-#else
-      if (!valid[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
-#endif
       float J[6];
       float raw;
       if (kDepth) {                                           // BS/kernel_opt_pose.cu:283-317
@@ -175,18 +164,9 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
         count += 1;
       }
       if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
-#if BSLAM_POSE_SPECULATE
         if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_samples_finish(kf, c, ds, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-#else
-        f2 color_pxy;
-        if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
-          f2 t1, t2;
-          project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
-          float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-#endif
+          descriptor_samples_finish(kf, c, ds, st(r, 12), st(r, 13), &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           gx1 *= c.cfx; gx2 *= c.cfx;
           gy1 *= c.cfy; gy2 *= c.cfy;
           descriptor_pose_jacobian(gx1, gy1, p.local, J);
