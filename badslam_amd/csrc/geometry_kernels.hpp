@@ -552,9 +552,6 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
 #ifndef BSLAM_GEOM_DESC_WAVES
 #define BSLAM_GEOM_DESC_WAVES 4
 #endif
-#ifndef BSLAM_GEOM_SPECULATE
-#define BSLAM_GEOM_SPECULATE 1
-#endif
 template <int R, int kPass, bool kDepth>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_DESC_WAVES))) void geometry_desc_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
                                                                  Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
@@ -590,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
       Proj p;
       DescSamples ds;
       bool has_desc = false;
-      if constexpr (kPass == 1 && BSLAM_GEOM_SPECULATE != 0) {
+      if constexpr (kPass == 1) {
         // the three quad gathers of the descriptor samples do not depend on the pixel record: issued with the record gather,
         // before the association test (see pose_accumulate_kernel)
         if (!on[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
@@ -621,15 +618,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
           const float w = depth_weight(raw);
           a[r][0] += w * dj * dj;
           a[r][5] += w * raw * dj;
-        }
-        if constexpr (BSLAM_GEOM_SPECULATE == 0) {
-          f2 color_pxy;
-          has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
-          if (has_desc) {
-            f2 t1, t2;
-            project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
-            ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
-          }
         }
         if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;

@@ -160,9 +160,11 @@ def measure(env, K, use_desc, steps, warmup, stack=None):
         # SQ_INSTS_VALU counts wave instructions; a wave64 op occupies a SIMD32 for >= 2 cycles (packed / fp64 / DPP more)
         roof["valu_issue_frac"] = valu * S * avg_kf_per_launch * 2 / (SIMD_COUNT * CLOCK_HZ * avg_launch_s)
     if roof["traffic"] is not None and avg_launch_s > 0:
-        # traffic was counted for a full-K launch; scale to this run's average launch
-        per_pair = roof["traffic"] / (S * K)
-        roof["hbm_traffic_frac"] = per_pair * S * avg_kf_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        # counted per average launch of the PMC run: scale by pairs to this run's average launch
+        per_pair = roof["traffic"] / (pmc_value(pmc, "pose_accumulate_kernel", "pairs_per_launch") or (S * K))
+        roof["traffic"] = per_pair * S * avg_kf_per_launch
+        roof["traffic_raw"] = (pmc_value(pmc, "pose_accumulate_kernel", "hbm_bytes_raw") or 0) / (pmc_value(pmc, "pose_accumulate_kernel", "pairs_per_launch") or (S * K)) * S * avg_kf_per_launch
+        roof["hbm_traffic_frac"] = roof["traffic"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
     geo_launches, geo_ms = prof["geometry"]
     roof["geometry_kernel"] = geometry_roofline(S, K, frac_inb, use_desc, steps, active_surfel_steps, geo_ms, pmc)
     act_launches, act_ms = prof["activation"]
@@ -307,7 +309,7 @@ def geometry_roofline(S, K, frac_inb, use_desc, steps, active_surfel_steps, tota
     per_step_s = total_ms / 1e3 / steps
     ach = nbytes / per_step_s / 1e9
     return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "us_per_step": per_step_s * 1e6, "algorithmic_bytes_per_step": nbytes,
-            "traffic": pmc_value(pmc, "geometry_kernel", "hbm_bytes")}
+            "traffic": pmc_value(pmc, "geometry_kernel", "hbm_bytes"), "traffic_raw": pmc_value(pmc, "geometry_kernel", "hbm_bytes_raw")}
 
 
 def pcg_block(stack, use_desc, dev_index, iterations=2):

@@ -47,7 +47,7 @@ for name, m in mean.items():
             e["valu_wave_insts_per_pair"] = m["SQ_INSTS_VALU"] / units[short]
     elif "SQ_INSTS_VALU" in m:
         e["valu_wave_insts"] = m["SQ_INSTS_VALU"]
-    kernels[name] = e
+    kernels[short if short in units else name] = e   # the dominant kernel under its plain name (one instantiation per workload)
 # the geometry iteration of one step = every dispatch of the geometry kernels of that step
 geo = [n for n in kernels if n.startswith("geometry_")]
 if geo:
