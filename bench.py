@@ -230,10 +230,26 @@ def main():
     env.cb = C.cast(None, abi.ALLREDUCE_FN)
     env.exchange = "none"
     if world > 1 and backend == "native":
-        uid = [badslam_amd.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
-        env.exchange = "RCCL ncclAllReduce inside libbadslam_hip (bslam_comm_init), on the BA stream"
+        ok = 1
+        try:
+            uid = [badslam_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], rank, world)
+        except Exception as e:   # reported, and agreed upon by all ranks below
+            ok = 0
+            print(f"rank {rank}: bslam_comm_init failed: {e!r}", file=sys.stderr, flush=True)
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
+            env.exchange = "RCCL ncclAllReduce inside libbadslam_hip (bslam_comm_init), on the BA stream"
+        else:
+            # some rank could not create the library's communicator: every rank falls back to the callback path over
+            # torch.distributed's RCCL group, and the line says so (config.exchange)
+            if ok:
+                ctx.comm_destroy()
+            hook = AllReduceHook(device=True, group=dist.new_group(backend="nccl"))
+            env.cb = hook.callback
+            env.exchange = "torch.distributed.all_reduce callback (nccl) -- FALLBACK: bslam_comm_init failed on some rank"
     elif world > 1:
         hook = AllReduceHook(device=True)
         env.cb = hook.callback
