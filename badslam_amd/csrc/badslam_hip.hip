@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -116,6 +117,8 @@ static SurfelRowsRW surfel_rows_rw(const bslam_buffer2d* s, const bslam_buffer2d
   o.d1 = row(BSLAM_SURFEL_DESCRIPTOR1); o.d2 = row(BSLAM_SURFEL_DESCRIPTOR2);
   o.active = active ? (uint8_t*)active->address : nullptr;
   o.size = size;
+  o.perm = nullptr;
+  o.ox = o.x; o.oy = o.y; o.oz = o.z; o.onormal = o.normal; o.od1 = o.d1; o.od2 = o.d2;
   return o;
 }
 
@@ -211,14 +214,33 @@ static uint32_t morton10(uint32_t v) {
   return v;
 }
 
-static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buffer2d* surfels, uint32_t surfels_size, int R, Schedule* out) {
+// Keyframe lists of at least this length walk the surfels in per-surfel Morton order (`perm`); shorter ones (the per-keyframe
+// entry points) keep coalesced surfel columns and only order the 256-column granules.
+constexpr int kPermMinKeyframes = 4;
+
+// Work order of the surfel kernels, cached per surfel buffer (address, size, pitch).  Long keyframe lists: a permutation of
+// the surfel columns sorted by the 30-bit Morton code of their positions (device radix sort, rocPRIM); the kernels then read a
+// sorted COPY of the surfel rows (prepare_surfels), so that their loads stay coalesced while the 64 surfels of a wave -- and the
+// R x 256 of a workgroup -- form a compact blob that projects onto a few cache lines in every keyframe.
+// Surfels are created in cell-raster order (BS/kernel_create_surfels.cu), i.e. 256 consecutive columns are a 1-pixel-high
+// strip hundreds of pixels long: K = 50, geometry iteration 350 -> 306 us (geometry-only), 701 -> 640 us (photometric), pose
+// kernels -4 ... -5 %.  Any permutation gives the same results up to the order of the per-keyframe sums; a cached order that has
+// gone stale (surfels moved) only costs locality.
+static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buffer2d* surfels, uint32_t surfels_size, int R, Schedule* out,
+                         int keyframe_count = 1, const uint32_t** perm_out = nullptr) {
   const uint32_t G = (surfels_size + kGranule - 1) / kGranule;
   out->granules = G;
   out->slots = (G + (uint32_t)R - 1) / (uint32_t)R;
   out->slots_per_xcd = (out->slots + 7) / 8;
   out->order = nullptr;
+  if (perm_out) *perm_out = nullptr;
   if (!ctx->use_schedule || G < 64) return BSLAM_OK;   // tiny problems: identity order
-  if (ctx->order_key_ptr == surfels->address && ctx->order_key_size == surfels_size && ctx->order_key_pitch == surfels->pitch) {
+  const bool want_perm = perm_out != nullptr && keyframe_count >= kPermMinKeyframes;
+  if (want_perm && ctx->perm_key_ptr == surfels->address && ctx->perm_key_size == surfels_size && ctx->perm_key_pitch == surfels->pitch) {
+    *perm_out = (const uint32_t*)ctx->perm.ptr;
+    return BSLAM_OK;
+  }
+  if (!want_perm && ctx->order_key_ptr == surfels->address && ctx->order_key_size == surfels_size && ctx->order_key_pitch == surfels->pitch) {
     out->order = (const uint32_t*)ctx->order.ptr;
     return BSLAM_OK;
   }
@@ -240,6 +262,31 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
     if (cent[g].w <= 0.f) continue;
     const float v[3] = {cent[g].x, cent[g].y, cent[g].z};
     for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], v[d]); hi[d] = std::max(hi[d], v[d]); }
+  }
+  if (want_perm) {
+    // keys + identity -> radix sort by key -> perm.  Layout of ctx->perm: perm[S] | keys[S] | keys_sorted[S] | ids[S] | sort scratch
+    const size_t n = surfels_size, words = (n + 63) & ~(size_t)63;
+    size_t temp_bytes = 0;
+    BSLAM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 30, stream));
+    if ((rc = ctx->perm.reserve(4 * words * sizeof(uint32_t) + temp_bytes + 256))) return rc;
+    uint32_t* d_perm = (uint32_t*)ctx->perm.ptr;
+    uint32_t* d_keys = d_perm + words;
+    uint32_t* d_keys_sorted = d_keys + words;
+    uint32_t* d_ids = d_keys_sorted + words;
+    void* d_temp = (void*)(d_ids + words);
+    f3 lo3{lo[0], lo[1], lo[2]}, inv3;
+    inv3.x = hi[0] > lo[0] ? 1.f / (hi[0] - lo[0]) : 0.f;
+    inv3.y = hi[1] > lo[1] ? 1.f / (hi[1] - lo[1]) : 0.f;
+    inv3.z = hi[2] > lo[2] ? 1.f / (hi[2] - lo[2]) : 0.f;
+    hipLaunchKernelGGL(surfel_morton_key_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, row(BSLAM_SURFEL_X), row(BSLAM_SURFEL_Y), row(BSLAM_SURFEL_Z),
+                       surfels_size, lo3, inv3, d_keys, d_ids);
+    BSLAM_HIP_TRY(hipGetLastError());
+    BSLAM_HIP_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, (const uint32_t*)d_keys, d_keys_sorted, (const uint32_t*)d_ids, d_perm, n, 0, 30, stream));
+    ctx->perm_key_ptr = surfels->address;
+    ctx->perm_key_size = surfels_size;
+    ctx->perm_key_pitch = surfels->pitch;
+    *perm_out = d_perm;
+    return BSLAM_OK;
   }
   std::vector<std::pair<uint32_t, uint32_t>> keyed(G);
   for (uint32_t g = 0; g < G; ++g) {
@@ -268,6 +315,50 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
   return BSLAM_OK;
 }
 
+// Schedule + the rows the surfel kernels of one API call read: the caller's rows, or (per-surfel order) the library's sorted
+// copy of them, rebuilt here because the caller may have changed the surfels since the last call (7 rows: 28 B per surfel).
+struct SurfelWork {
+  Schedule sc;
+  SurfelRows rows;          // what the kernels read
+  const uint32_t* perm;     // position in `rows` -> caller's column, or nullptr
+};
+static int prepare_surfels(bslam_context* ctx, hipStream_t stream, const bslam_buffer2d* surfels, uint32_t surfels_size, int R, int keyframe_count, SurfelWork* w,
+                           bool need_descriptor_rows = true) {
+  int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &w->sc, keyframe_count, &w->perm);
+  if (rc) return rc;
+  w->rows = surfel_rows(surfels, surfels_size);
+  if (!w->perm) return BSLAM_OK;
+  const size_t pitch = ((size_t)surfels_size + 63) & ~(size_t)63;
+  if ((rc = ctx->sorted_rows.reserve(7 * pitch * sizeof(float)))) return rc;
+  float* out = (float*)ctx->sorted_rows.ptr;
+  // the copy costs a scattered 4-byte read per row and surfel: rows the call's kernels never read (radius, descriptors in a
+  // geometry-only call) are left out
+  if (need_descriptor_rows)
+    hipLaunchKernelGGL(permute_surfel_rows_kernel<7>, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
+                       surfels->pitch / sizeof(float), out, pitch);
+  else
+    hipLaunchKernelGGL(permute_surfel_rows_kernel<4>, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
+                       surfels->pitch / sizeof(float), out, pitch);
+  BSLAM_HIP_TRY(hipGetLastError());
+  w->rows.x = out; w->rows.y = out + pitch; w->rows.z = out + 2 * pitch;
+  w->rows.normal = (const uint32_t*)(out + 3 * pitch);
+  w->rows.radius_squared = out + 4 * pitch;
+  w->rows.d1 = out + 5 * pitch; w->rows.d2 = out + 6 * pitch;
+  return BSLAM_OK;
+}
+// The same for kernels that also update surfels: reads (and write-through) on w.rows, updates to the caller's rows as well.
+static SurfelRowsRW surfel_rows_rw(const SurfelWork& w, const bslam_buffer2d* surfels, const bslam_buffer2d* active, uint32_t size) {
+  SurfelRowsRW o = surfel_rows_rw(surfels, active, size);
+  o.perm = w.perm;
+  if (w.perm) {
+    o.x = (float*)w.rows.x; o.y = (float*)w.rows.y; o.z = (float*)w.rows.z;
+    o.normal = (uint32_t*)w.rows.normal;
+    o.radius_squared = w.rows.radius_squared;
+    o.d1 = (float*)w.rows.d1; o.d2 = (float*)w.rows.d2;
+  }
+  return o;
+}
+
 // Chooses how many keyframes one block walks: enough blocks to fill 256 CUs several times over.
 static int choose_kfs_per_block(int tiles, int kf_count) {
 #ifndef BSLAM_POSE_TARGET_BLOCKS
@@ -287,13 +378,18 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
   return per_block;
 }
 
+// `work`: the prepared schedule + rows of this API call (prepare_surfels; the batched Gauss-Newton loop prepares them once for
+// all its iterations), or nullptr to prepare them here.
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
-                                  int* tiles_out, bool reduce_rows = true) {
-  Schedule sc;
-  const int R = use_desc ? kPoseRDesc : kPoseRGeo;
-  int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &sc);
-  if (rc) return rc;
+                                  int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr) {
+  SurfelWork local;
+  int rc = BSLAM_OK;
+  if (!work) {
+    if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_desc ? kPoseRDesc : kPoseRGeo, kf_count, &local, use_desc != 0))) return rc;
+    work = &local;
+  }
+  const Schedule sc = work->sc;
   const int tiles = (int)sc.slots;
   *tiles_out = tiles;
   const int rows_per_kf = tiles * (kPoseThreads / 64);   // one partial row per (slot, wave)
@@ -305,7 +401,7 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   const int per_block = choose_kfs_per_block(tiles, kf_count);
   const unsigned chunks = (unsigned)((kf_count + per_block - 1) / per_block);
   dim3 grid(8u * sc.slots_per_xcd * chunks);
-  const SurfelRows rows = surfel_rows(surfels, surfels_size);
+  const SurfelRows rows = work->rows;
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   float* partials = (float*)ctx->partials.ptr;
   // tuning aid: BSLAM_DEBUG_POSE_LDS = bytes of (unused) dynamic LDS per block, to cap the blocks per CU without touching the code
@@ -405,7 +501,7 @@ int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
   bslam_comm_destroy(ctx);
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->perm.release(); ctx->sorted_rows.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
@@ -486,6 +582,7 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->use_schedule = enable != 0;
   ctx->order_key_ptr = nullptr;
+  ctx->perm_key_ptr = nullptr;
   return BSLAM_OK;
 }
 
@@ -752,6 +849,9 @@ int bslam_estimate_frame_poses_batched(
                      (const PoseState*)d_states, (KfDev*)ctx->kf_table.ptr);
   BSLAM_HIP_TRY(hipGetLastError());
 
+  SurfelWork work;   // schedule + (sorted) surfel rows: the surfels do not change during the loop
+  if (surfels_size > 0 && (rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? kPoseRDesc : kPoseRGeo, keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
+
   // One Gauss-Newton iteration of all unconverged keyframes, ending with the number of keyframes still
   // unconverged on its way to h_active[it % 4].
   auto enqueue_iteration = [&](int it) -> int {
@@ -762,7 +862,7 @@ int bslam_estimate_frame_poses_batched(
     if (it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
     if (fused) {
       int tiles = 0;
-      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false);
+      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work);
       if (r) return r;
       hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
                          tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
@@ -770,7 +870,7 @@ int bslam_estimate_frame_poses_batched(
     } else {
       if (surfels_size > 0) {
         int tiles = 0;
-        int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles);
+        int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, true, &work);
         if (r) return r;
       } else {
         int r = ctx->coeffs.reserve((size_t)keyframe_count * kRow * sizeof(float));
@@ -842,8 +942,11 @@ int bslam_update_surfel_activation(
   int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
-  Schedule sc;
-  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  // granule order, not the per-surfel one: a surfel stops at its first associated keyframe (about 3 of K visited), which
+  // does not pay for a sorted copy of the rows
+  SurfelWork work;
+  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, 1, 1, &work, false))) return rc;
+  const Schedule sc = work.sc;
   {
     ProfScope prof(ctx, stream, BSLAM_PROF_ACTIVATION);
     const size_t counter_slots = 2 * (size_t)(8u * sc.slots_per_xcd);
@@ -857,10 +960,10 @@ int bslam_update_surfel_activation(
     }
     if (ctx->profiling && ctx->prof_counters.ptr)
       hipLaunchKernelGGL(activation_kernel<true>, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
-                         surfel_rows_rw(surfels, active_surfels, surfels_size), (unsigned long long*)ctx->prof_counters.ptr);
+                         surfel_rows_rw(work, surfels, active_surfels, surfels_size), (unsigned long long*)ctx->prof_counters.ptr);
     else
       hipLaunchKernelGGL(activation_kernel<false>, dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
-                         surfel_rows_rw(surfels, active_surfels, surfels_size), (unsigned long long*)nullptr);
+                         surfel_rows_rw(work, surfels, active_surfels, surfels_size), (unsigned long long*)nullptr);
   }
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
@@ -875,10 +978,11 @@ int bslam_update_surfel_normals(
   int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
-  Schedule sc;
-  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, 1, &sc))) return rc;
+  SurfelWork work;
+  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, 1, keyframe_count, &work, false))) return rc;
+  const Schedule sc = work.sc;
   hipLaunchKernelGGL((geometry_kernel<0, true>), dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
-                     surfel_rows_rw(surfels, active_surfels, surfels_size));
+                     surfel_rows_rw(work, surfels, active_surfels, surfels_size));
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -906,14 +1010,15 @@ int bslam_optimize_geometry_iteration(
 #ifndef BSLAM_GEOM_R
 #define BSLAM_GEOM_R 3
 #endif
-  Schedule sc;
 #ifndef BSLAM_GEOM_R_DESC
 #define BSLAM_GEOM_R_DESC 2
 #endif
-  if ((rc = make_schedule(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? (ctx->geom_desc_legacy ? 1 : BSLAM_GEOM_R_DESC) : BSLAM_GEOM_R, &sc))) return rc;
+  SurfelWork work;
+  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? (ctx->geom_desc_legacy ? 1 : BSLAM_GEOM_R_DESC) : BSLAM_GEOM_R, keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
+  const Schedule sc = work.sc;
   const dim3 grid(8u * sc.slots_per_xcd), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
-  const SurfelRowsRW rows = surfel_rows_rw(surfels, active_surfels, surfels_size);
+  const SurfelRowsRW rows = surfel_rows_rw(work, surfels, active_surfels, surfels_size);
   {
   ProfScope prof(ctx, stream, 1);
   if (!use_descriptor_residuals) {

@@ -141,6 +141,11 @@ struct bslam_context {
   void* comm = nullptr;                     // bslam_comm_init: RCCL communicator (ncclComm_t) of the surfel-sharded run
   int comm_rank = 0, comm_world = 1;
   bslam::Slab order;
+  bslam::Slab perm;          // per-surfel Morton order (+ sort scratch), cached like `order`
+  bslam::Slab sorted_rows;   // the seven persistent surfel rows in that order, rebuilt by every call that uses it
+  const void* perm_key_ptr = nullptr;
+  uint32_t perm_key_size = 0;
+  size_t perm_key_pitch = 0;
   bool use_schedule = true;
   const void* order_key_ptr = nullptr;
   uint32_t order_key_size = 0;

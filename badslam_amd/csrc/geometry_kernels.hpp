@@ -13,6 +13,9 @@
 
 namespace bslam {
 
+// Rows the surfel kernels read and update.  With a per-surfel work order (`perm`, make_schedule) x .. d2 are the library's
+// sorted copy of the caller's rows -- position j of the copy is the caller's column perm[j] -- and every update is written to
+// both: the copy (later passes of the same call read it) and the caller's rows o*.  `active` is always the caller's.
 struct SurfelRowsRW {
   float* x; float* y; float* z;
   uint32_t* normal;
@@ -20,7 +23,35 @@ struct SurfelRowsRW {
   float* d1; float* d2;
   uint8_t* active;
   uint32_t size;
+  const uint32_t* perm;    // nullptr: x .. d2 ARE the caller's rows
+  float* ox; float* oy; float* oz;
+  uint32_t* onormal;
+  float* od1; float* od2;
 };
+__device__ __forceinline__ uint32_t column_of(const SurfelRowsRW& s, uint32_t j) { return s.perm ? s.perm[j] : j; }
+__device__ __forceinline__ void store_normal(const SurfelRowsRW& s, uint32_t j, uint32_t packed) {
+  s.normal[j] = packed;
+  if (s.perm) s.onormal[s.perm[j]] = packed;
+}
+__device__ __forceinline__ void store_position(const SurfelRowsRW& s, uint32_t j, f3 p) {
+  s.x[j] = p.x; s.y[j] = p.y; s.z[j] = p.z;
+  if (s.perm) { const uint32_t o = s.perm[j]; s.ox[o] = p.x; s.oy[o] = p.y; s.oz[o] = p.z; }
+}
+__device__ __forceinline__ void store_descriptor1(const SurfelRowsRW& s, uint32_t j, float v) { s.d1[j] = v; if (s.perm) s.od1[s.perm[j]] = v; }
+__device__ __forceinline__ void store_descriptor2(const SurfelRowsRW& s, uint32_t j, float v) { s.d2[j] = v; if (s.perm) s.od2[s.perm[j]] = v; }
+
+// Sorted copy of the seven persistent surfel rows the pair kernels read: out row r, position j = in row r, column perm[j].
+// kRows = 4: position + normal only (what the geometry-only kernels read).
+template <int kRows>
+__global__ __launch_bounds__(256) void permute_surfel_rows_kernel(const uint32_t* __restrict__ perm, uint32_t size, const float* __restrict__ in, size_t in_pitch_floats,
+                                                                 float* __restrict__ out, size_t out_pitch_floats) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= size) return;
+  const uint32_t i = perm[j];
+  const int rows[7] = {BSLAM_SURFEL_X, BSLAM_SURFEL_Y, BSLAM_SURFEL_Z, BSLAM_SURFEL_NORMAL, BSLAM_SURFEL_RADIUS_SQUARED, BSLAM_SURFEL_DESCRIPTOR1, BSLAM_SURFEL_DESCRIPTOR2};
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) out[(size_t)r * out_pitch_floats + j] = in[(size_t)rows[r] * in_pitch_floats + i];
+}
 
 // SetSurfelInactiveKernel + K x DetermineActiveSurfelsKernel (BS/kernel_surfel_activation.cu:38-79)
 // kCount (bslam_profile_enable): additionally adds the number of (surfel, keyframe) pairs actually visited -- the walk stops at
@@ -36,7 +67,8 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
   uint32_t visited = 0, activated = 0;
   if (!kCount && i >= s.size) return;
   if (i < s.size) {
-    uint8_t flag = s.active[i] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
+    const uint32_t col = column_of(s, i);
+    uint8_t flag = s.active[col] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
     const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
     const f3 gn = unpack_normal(s.normal[i]);
     for (int k = 0; k < kf_count; ++k) {
@@ -46,7 +78,7 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
       Proj p;
       if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; activated = 1; break; }
     }
-    s.active[i] = flag;
+    s.active[col] = flag;
   }
   if (kCount) {
     __shared__ uint32_t sm[2][4];
@@ -78,6 +110,32 @@ __global__ __launch_bounds__(256) void granule_centroid_kernel(const float* __re
     const float inv = s3 > 0.f ? 1.f / s3 : 0.f;
     out[blockIdx.x] = make_float4(s0 * inv, s1 * inv, s2 * inv, s3);
   }
+}
+
+// 30-bit Morton key of every surfel position (10 bits per axis inside the box lo .. lo + 1 / inv_span; invalid positions
+// last), with the identity as payload: input of the per-surfel order of make_schedule.
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void surfel_morton_key_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t size,
+                                                                f3 lo, f3 inv_span, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size) return;
+  const float a = x[i], b = y[i], cc = z[i];
+  uint32_t key = 0x3fffffffu;
+  if (a == a && b == b && cc == cc && fabsf(a) < 1e18f && fabsf(b) < 1e18f && fabsf(cc) < 1e18f) {
+    const uint32_t qx = (uint32_t)__builtin_amdgcn_fmed3f((a - lo.x) * inv_span.x * 1023.f, 0.f, 1023.f);
+    const uint32_t qy = (uint32_t)__builtin_amdgcn_fmed3f((b - lo.y) * inv_span.y * 1023.f, 0.f, 1023.f);
+    const uint32_t qz = (uint32_t)__builtin_amdgcn_fmed3f((cc - lo.z) * inv_span.z * 1023.f, 0.f, 1023.f);
+    key = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+  }
+  keys[i] = key;
+  ids[i] = i;
 }
 
 // Association probe: out[i] = py * width + px or 0xffffffff.
@@ -265,7 +323,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
   if (i >= s.size) return;
-  if (!(s.active[i] & BSLAM_SURFEL_ACTIVE_FLAG)) return;
+  if (!(s.active[column_of(s, i)] & BSLAM_SURFEL_ACTIVE_FLAG)) return;
   f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
   uint32_t packed = s.normal[i];
   f3 gn = unpack_normal(packed);
@@ -289,7 +347,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     if (cnt >= 1) {
       const float inv = 1.f / cnt;
       packed = pack_normal(mk3(inv * sx, inv * sy, inv * sz));
-      s.normal[i] = packed;
+      store_normal(s, i, packed);
       gn = unpack_normal(packed);
     }
   }
@@ -315,7 +373,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     if (H > 1e-6f) {
       const float t = -1.f * b / H;
       gp = add3(gp, scale3(t, gn));
-      s.x[i] = gp.x; s.y[i] = gp.y; s.z[i] = gp.z;
+      store_position(s, i, gp);
     }
     return;
   }
@@ -380,10 +438,10 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
     const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
     if (x0 != 0) {
       gp = sub3(gp, scale3(x0, gn));
-      s.x[i] = gp.x; s.y[i] = gp.y; s.z[i] = gp.z;
+      store_position(s, i, gp);
     }
-    if (x1 != 0) s.d1[i] = fmaxf(-180.f, fminf(180.f, desc1 - x1));
-    if (x2 != 0) s.d2[i] = fmaxf(-180.f, fminf(180.f, desc2 - x2));
+    if (x1 != 0) store_descriptor1(s, i, fmaxf(-180.f, fminf(180.f, desc1 - x1)));
+    if (x2 != 0) store_descriptor2(s, i, fmaxf(-180.f, fminf(180.f, desc2 - x2)));
   }
 }
 
@@ -406,7 +464,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
   for (int r = 0; r < R; ++r) {
     idx[r] = surfel_of_slot(sc, slot, r, R);
     on[r] = idx[r] < s.size;
-    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    if (on[r]) on[r] = (s.active[column_of(s, idx[r])] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
     const uint32_t j = on[r] ? idx[r] : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
@@ -435,7 +493,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
       if (on[r] && cnt[r] >= 1) {
         const float inv = 1.f / cnt[r];
         const uint32_t packed = pack_normal(mk3(inv * sx[r], inv * sy[r], inv * sz[r]));
-        s.normal[idx[r]] = packed;
+        store_normal(s, idx[r], packed);
         gn[r] = unpack_normal(packed);
       }
     }
@@ -465,7 +523,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
     if (on[r] && H[r] > 1e-6f) {
       const float t = -1.f * b[r] / H[r];
       const f3 np = add3(gp[r], scale3(t, gn[r]));
-      s.x[idx[r]] = np.x; s.y[idx[r]] = np.y; s.z[idx[r]] = np.z;
+      store_position(s, idx[r], np);
     }
   }
 }
@@ -487,7 +545,7 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
   for (int r = 0; r < R; ++r) {
     idx[r] = surfel_of_slot(sc, slot, r, R);
     on[r] = idx[r] < s.size;
-    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    if (on[r]) on[r] = (s.active[column_of(s, idx[r])] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
     const uint32_t j = on[r] ? idx[r] : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
@@ -533,12 +591,12 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
     } else if (kPass == 0) {
       if (a3[r] >= 1) {
         const float inv = 1.f / a3[r];
-        s.normal[j] = pack_normal(mk3(inv * a0[r], inv * a1[r], inv * a2[r]));
+        store_normal(s, j, pack_normal(mk3(inv * a0[r], inv * a1[r], inv * a2[r])));
       }
     } else if (a0[r] > 1e-6f) {
       const float t = -1.f * a1[r] / a0[r];
       const f3 np = add3(gp[r], scale3(t, gn[r]));
-      s.x[j] = np.x; s.y[j] = np.y; s.z[j] = np.z;
+      store_position(s, j, np);
     }
   }
 }
@@ -567,7 +625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
   for (int r = 0; r < R; ++r) {
     idx[r] = surfel_of_slot(sc, slot, r, R);
     on[r] = idx[r] < s.size;
-    if (on[r]) on[r] = (s.active[idx[r]] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
+    if (on[r]) on[r] = (s.active[column_of(s, idx[r])] & BSLAM_SURFEL_ACTIVE_FLAG) != 0;
     const uint32_t j = on[r] ? idx[r] : 0;
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
@@ -651,7 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     } else if constexpr (kPass == 0) {
       if (a[r][3] >= 1) {
         const float inv = 1.f / a[r][3];
-        s.normal[j] = pack_normal(mk3(inv * a[r][0], inv * a[r][1], inv * a[r][2]));
+        store_normal(s, j, pack_normal(mk3(inv * a[r][0], inv * a[r][1], inv * a[r][2])));
       }
     } else {
       float H00 = a[r][0], H01 = a[r][1], H02 = a[r][2], H11 = a[r][3], H12 = 0.f, H22 = a[r][4];
@@ -670,10 +728,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
       const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
       if (x0 != 0) {
         const f3 np = sub3(gp[r], scale3(x0, gn[r]));
-        s.x[j] = np.x; s.y[j] = np.y; s.z[j] = np.z;
+        store_position(s, j, np);
       }
-      if (x1 != 0) s.d1[j] = fmaxf(-180.f, fminf(180.f, desc1[r] - x1));
-      if (x2 != 0) s.d2[j] = fmaxf(-180.f, fminf(180.f, desc2[r] - x2));
+      if (x1 != 0) store_descriptor1(s, j, fmaxf(-180.f, fminf(180.f, desc1[r] - x1)));
+      if (x2 != 0) store_descriptor2(s, j, fmaxf(-180.f, fminf(180.f, desc2[r] - x2)));
     }
   }
 }

@@ -53,6 +53,9 @@ struct PcgParams {
   // fp64 the order only matters below 1e-16 relative, so the rounded sums are the same on every run.
   double* cf_acc0; double* cf_acc1;
   uint32_t cf_cells;
+  // per-surfel work order (make_schedule): the surfel kernels read the library's sorted copy of the surfel rows; position j of
+  // it is the caller's column perm[j], which is what the unknown layout counts in (nullptr: identity)
+  const uint32_t* perm;
 };
 
 __device__ __forceinline__ uint32_t kf_pose_unknown_index(int gauge, int id) {   // BS/direct_ba_pcg.cc:329-337
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 #pragma unroll
     for (int r = 0; r < kPcgR; ++r) {
       if (!valid[r]) continue;
-      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * (P.perm ? P.perm[idx[r]] : idx[r]);
       P.r[base] = ar[r][0];
       P.M[base] = aM[r][0];
       if (kDesc) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
 #pragma unroll
     for (int j = 0; j < 3; ++j) { ps[r][j] = 0.f; ag[r][j] = 0.f; }
     if (P.optimize_geometry) {
-      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * (P.perm ? P.perm[idx[r]] : idx[r]);
       ps[r][0] = P.p[base];
       if (kDesc) { ps[r][1] = P.p[base + 1]; ps[r][2] = P.p[base + 2]; }
     }
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
 #pragma unroll
     for (int r = 0; r < kPcgR; ++r) {
       if (!valid[r]) continue;
-      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * idx[r];
+      const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * (P.perm ? P.perm[idx[r]] : idx[r]);
       P.g[base] = ag[r][0];
       if (kDesc) { P.g[base + 1] = ag[r][1]; P.g[base + 2] = ag[r][2]; }
     }

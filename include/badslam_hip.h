@@ -168,10 +168,14 @@ int bslam_set_texture_mode(bslam_context* ctx, int mode);
 int bslam_set_keyframe_cache(bslam_context* ctx, int enable);
 int bslam_invalidate_keyframe_cache(bslam_context* ctx);
 
-/* XCD-aware scheduling (default on): surfel granules are visited along a Morton curve of their
- * centroids, one contiguous range per XCD, so that every XCD's L2 only sees the part of each
- * keyframe image its part of the scene projects to.  Results do not depend on it except for the
- * summation order of the per-keyframe sums; 0 restores index order (A/B measurements). */
+/* XCD-aware scheduling (default on): surfels are visited along a Morton curve, one contiguous range
+ * per XCD, so that every XCD's L2 only sees the part of each keyframe image its part of the scene
+ * projects to.  Calls with at least 4 keyframes order the individual surfels by the Morton code of
+ * their positions (device radix sort, cached per surfel buffer) and read a sorted copy of the surfel
+ * rows, so that a wave's 64 surfels project onto a few cache lines in every keyframe; shorter
+ * keyframe lists (the per-keyframe entry points) order 256-column granules by their centroids.
+ * Results do not depend on it except for the summation order of the per-keyframe sums; 0 restores
+ * index order (A/B measurements, bit-for-bit comparisons between entry points). */
 int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
 
 /* Kernel timing for the roofline line of bench.py (the role of the reference's cudaEvent

@@ -140,13 +140,23 @@ def test_batched_coefficients_match_per_keyframe_oracle(multi):
 
 
 def test_batched_equals_single_keyframe_entry_point(multi):
-    """The reference-shaped per-keyframe entry point and the batched one run the same kernel:
-    deterministic sums, identical bits."""
+    """The reference-shaped per-keyframe entry point and the batched one run the same kernel: deterministic sums, and -- in
+    the same work order (index order; by default long keyframe lists use a per-surfel Morton order, short ones a granule
+    order) -- identical bits."""
     scene, hip = multi
     Hb, counts = hip.accumulate_pose_batched()
     for k in range(len(scene.keyframes)):
         one = hip.accumulate_pose(k)
-        assert np.array_equal(one["H"], Hb[k, :21]) and np.array_equal(one["b"], Hb[k, 21:])
+        assert rel_close(one["H"], Hb[k, :21], rel=1e-5) and one["count"] == counts[k]
+    badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, 0))
+    try:
+        Hi, ci = hip.accumulate_pose_batched()
+        for k in range(len(scene.keyframes)):
+            one = hip.accumulate_pose(k)
+            assert np.array_equal(one["H"], Hi[k, :21]) and np.array_equal(one["b"], Hi[k, 21:])
+        assert np.array_equal(ci, counts)
+    finally:
+        badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, 1))
     Hb2, _ = hip.accumulate_pose_batched()
     assert np.array_equal(Hb, Hb2), "sums must be reproducible run to run"
 

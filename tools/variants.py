@@ -42,7 +42,7 @@ def bench(args):
             j = json.loads(r.stdout.strip().splitlines()[-1])
             roof = j["roofline"]
             print(f"{name:24s} ms/step {j['ms_per_step']:9.3f}  pose_acc {roof['avg_launch_us']:9.1f} us (frac {roof['frac']:.3f})  geometry {roof['geometry_kernel']['us_per_step']:9.1f} us/step "
-                  f"(frac {roof['geometry_kernel']['frac']:.3f})", flush=True)
+                  f"(frac {roof['geometry_kernel']['frac']:.3f})  activation {roof['activation_kernel']['avg_launch_us']:7.1f} us", flush=True)
         except Exception:
             print(name, "FAILED", r.stdout[-500:], r.stderr[-1500:], flush=True)
 
