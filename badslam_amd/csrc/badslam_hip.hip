@@ -372,7 +372,7 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
   // Large surfel counts give enough blocks with one chunk, but then every block walks the whole keyframe list and the
   // resident blocks spread over all of it; a cap keeps the blocks in flight (chunk-major order) on a few keyframes.
 #ifndef BSLAM_POSE_MAX_KFS_PER_BLOCK
-#define BSLAM_POSE_MAX_KFS_PER_BLOCK 16   /* measured flat optimum 12 ... 32 (K = 200: -7 %, K = 300 photometric: -13 % kernel time); 0: no cap */
+#define BSLAM_POSE_MAX_KFS_PER_BLOCK 32   /* measured flat optimum 12 ... 32 (K = 200: -7 %, K = 300 photometric: -13 % kernel time; with the per-surfel order 32: 15.5 ms, 16: 15.8, 8: 16.2, 64: 15.6); 0: no cap */
 #endif
   if (BSLAM_POSE_MAX_KFS_PER_BLOCK > 0 && per_block > BSLAM_POSE_MAX_KFS_PER_BLOCK) per_block = BSLAM_POSE_MAX_KFS_PER_BLOCK;
   return per_block;
@@ -1022,32 +1022,22 @@ int bslam_optimize_geometry_iteration(
   {
   ProfScope prof(ctx, stream, 1);
   if (!use_descriptor_residuals) {
-    // at most one resident grid per launch (5 workgroups of 256 threads per CU at this kernel's register count), so that the
-    // workgroups of a launch walk the keyframe table in near lockstep
-#ifndef BSLAM_GEOM_WG_PER_CU
-#define BSLAM_GEOM_WG_PER_CU 5
-#endif
-    const uint32_t per_launch = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU) / 8u);   // slots per XCD and launch
-    // keyframes per launch (bslam_set_geometry_keyframe_chunk; default 128: K = 200: geometry kernel 6.9 -> 5.5 ms)
-    const int kf_chunk = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 128 : ctx->geom_kf_chunk);
-    float* acc = nullptr;
-    uint32_t acc_pitch = 0;
-    if (kf_chunk > 0 && keyframe_count > kf_chunk) {
-      acc_pitch = (surfels_size + 63u) & ~63u;
+    // One launch over all surfels and keyframes.  (Round 1 split the work into resident grids and keyframe chunks of 128 to keep
+    // the workgroups in lockstep on the keyframe table; with the per-surfel work order that costs 24 % at K = 200 and nothing is
+    // gained by chunks, K = 1000 included.  bslam_set_geometry_keyframe_chunk still selects chunked launches, per-surfel sums
+    // carried in library scratch, bit-identical results.)
+    const int kf_chunk = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 0 : ctx->geom_kf_chunk);
+    if (kf_chunk <= 0 || keyframe_count <= kf_chunk) {
+      hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), grid, block, 0, stream, c, kfs, keyframe_count, sc, 0u, rows);
+    } else {
+      const uint32_t acc_pitch = (surfels_size + 63u) & ~63u;
       if ((rc = ctx->exchange.reserve((size_t)acc_pitch * 4 * sizeof(float)))) return rc;
-      acc = (float*)ctx->exchange.ptr;
-    }
-    for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
-      const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
-      if (!acc) {
-        hipLaunchKernelGGL((geometry_position_kernel<BSLAM_GEOM_R>), dim3(8u * n), block, 0, stream, c, kfs, keyframe_count, sc, first, rows);
-        continue;
-      }
+      float* acc = (float*)ctx->exchange.ptr;
       for (int pass = 0; pass < 2; ++pass) {
         for (int k0 = 0; k0 < keyframe_count; k0 += kf_chunk) {
           const int k1 = std::min(keyframe_count, k0 + kf_chunk);
-          if (pass == 0) hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 0>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, first, rows, acc, acc_pitch);
-          else hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 1>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, first, rows, acc, acc_pitch);
+          if (pass == 0) hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 0>), grid, block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, 0u, rows, acc, acc_pitch);
+          else hipLaunchKernelGGL((geometry_chunk_kernel<BSLAM_GEOM_R, 1>), grid, block, 0, stream, c, kfs, k0, k1, k0 == 0, k1 == keyframe_count, sc, 0u, rows, acc, acc_pitch);
         }
       }
     }
@@ -1056,16 +1046,10 @@ int bslam_optimize_geometry_iteration(
     if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
     else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
   } else {
-    // photometric iteration: BSLAM_GEOM_R_DESC surfels per thread, at most one resident grid per launch, keyframe chunks with the
-    // per-surfel sums carried in scratch (4 floats for the normals pass, 8 for the joint position + descriptor pass)
-#ifndef BSLAM_GEOM_WG_PER_CU_DESC
-#define BSLAM_GEOM_WG_PER_CU_DESC 4
-#endif
-    const uint32_t resident = std::max<uint32_t>(1u, (uint32_t)(ctx->cu_count * BSLAM_GEOM_WG_PER_CU_DESC) / 8u);   // slots per XCD that fit at once
-    const uint32_t launches = (sc.slots_per_xcd + resident - 1) / resident;
-    const uint32_t per_launch = std::max<uint32_t>(1u, (sc.slots_per_xcd + launches - 1) / std::max(1u, launches));     // equal shares
-    // keyframes per launch: default 64 (K = 300: 26.7 ms per iteration with 128, 24.6 with 64, 25.3 with 32)
-    const int kf_chunk_set = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 64 : ctx->geom_kf_chunk);
+    // photometric iteration: BSLAM_GEOM_R_DESC surfels per thread, one launch per pass over all surfels and keyframes (K = 300:
+    // 22.0 ms per iteration with resident-grid launches, 16.5 ms with one); optional keyframe chunks with the per-surfel sums
+    // carried in scratch (4 floats for the normals pass, 8 for the joint position + descriptor pass)
+    const int kf_chunk_set = equal_keyframe_chunks(keyframe_count, ctx->geom_kf_chunk < 0 ? 0 : ctx->geom_kf_chunk);
     const int kf_chunk = kf_chunk_set > 0 ? kf_chunk_set : keyframe_count;
     float* acc = nullptr;
     uint32_t acc_pitch = 0;
@@ -1074,16 +1058,13 @@ int bslam_optimize_geometry_iteration(
       if ((rc = ctx->exchange.reserve((size_t)acc_pitch * 8 * sizeof(float)))) return rc;
       acc = (float*)ctx->exchange.ptr;
     }
-    for (uint32_t first = 0; first < sc.slots_per_xcd; first += per_launch) {
-      const uint32_t n = std::min(per_launch, sc.slots_per_xcd - first);
-      for (int pass = 0; pass < 2; ++pass) {
-        for (int k0 = 0; k0 < keyframe_count; k0 += kf_chunk) {
-          const int k1 = std::min(keyframe_count, k0 + kf_chunk);
-          const int fc = k0 == 0, lc = k1 == keyframe_count;
-          if (pass == 0) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 0, true>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
-          else if (use_depth_residuals) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, true>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
-          else hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, false>), dim3(8u * n), block, 0, stream, c, kfs, k0, k1, fc, lc, sc, first, rows, acc, acc_pitch);
-        }
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int k0 = 0; k0 < keyframe_count; k0 += kf_chunk) {
+        const int k1 = std::min(keyframe_count, k0 + kf_chunk);
+        const int fc = k0 == 0, lc = k1 == keyframe_count;
+        if (pass == 0) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 0, true>), grid, block, 0, stream, c, kfs, k0, k1, fc, lc, sc, 0u, rows, acc, acc_pitch);
+        else if (use_depth_residuals) hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, true>), grid, block, 0, stream, c, kfs, k0, k1, fc, lc, sc, 0u, rows, acc, acc_pitch);
+        else hipLaunchKernelGGL((geometry_desc_chunk_kernel<BSLAM_GEOM_R_DESC, 1, false>), grid, block, 0, stream, c, kfs, k0, k1, fc, lc, sc, 0u, rows, acc, acc_pitch);
       }
     }
   }

@@ -120,7 +120,7 @@ struct bslam_context {
   bslam::Slab pose_state;    // PoseState[K]
   bslam::Slab misc;          // small device scalars
   bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step; or the PCG path's fp64 cell sums
-  int geom_kf_chunk = -1;    // geometry iteration: keyframes per launch (0: one launch for the whole list; -1: default, 128 geometry-only / 64 photometric)
+  int geom_kf_chunk = -1;    // geometry iteration: keyframes per launch (0: one launch for the whole list; -1: default = one launch)
   bool geom_desc_legacy = false;   // photometric geometry iteration as one launch of geometry_kernel<2> (A/B measurements, parity tests)
   int intr_cells_owner = 0;  // 0: intrinsics step (zeroes per call), 1: PCG (kept zero between calls)
   size_t intr_cells_cells = 0;

@@ -320,7 +320,7 @@ int bslam_debug_association(
 
 /* Tuning knob of bslam_optimize_geometry_iteration: long keyframe lists are walked in (equally long) launches of at most
  * `keyframes_per_launch` keyframes, with the per-surfel sums carried in library scratch (results are bit-identical to a
- * single launch).  -1 = the library's default (128 geometry-only, 64 photometric); 0 = always one launch. */
+ * single launch).  -1 = the library's default (one launch); 0 = always one launch. */
 int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch);
 /* 1: the photometric geometry iteration runs as ONE launch of the one-surfel-per-thread kernel over the whole keyframe list
  * (the round-1 form; bit-identical results, kept for A/B measurements and as the parity reference of the chunked form). */

@@ -121,12 +121,13 @@ def test_configs4_geometry_1000_keyframes_20m_surfels_properties():
     assert int(act.sum()) > 0.99 * dev.surfels_size
     assert torch.equal(run.activation(), act)
     check_additive_and_deterministic(run, 1e-4)
-    # geometry iteration: keyframe chunks of 128 (default) vs one launch over the 1000 keyframes, bit-identical
+    # geometry iteration: keyframe chunks of 128 vs one launch over the 1000 keyframes (default), bit-identical
     start = dev.surfels.clone()
+    badslam_amd.check(run.L.bslam_set_geometry_keyframe_chunk(run.ctx.handle, 128))
     run.geometry()
     chunked = dev.surfels[:8].clone()
     dev.surfels.copy_(start)
-    badslam_amd.check(run.L.bslam_set_geometry_keyframe_chunk(run.ctx.handle, 0))
+    badslam_amd.check(run.L.bslam_set_geometry_keyframe_chunk(run.ctx.handle, -1))
     run.geometry()
     assert torch.equal(dev.surfels[:8].view(torch.int32), chunked.view(torch.int32))
     assert not torch.equal(chunked[:3], start[:3])

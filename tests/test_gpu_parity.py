@@ -490,7 +490,7 @@ def test_photometric_geometry_chunked_equals_single_launch(oracle):
         hip.optimize_geometry_iteration()
         results[name] = hip.d.surfels_np()[:8, :n].copy()
     badslam_amd.check(L.bslam_set_geometry_descriptor_legacy(h, 0))
-    badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, 128))
+    badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, -1))
     for name in ("chunk16", "chunk5", "one chunk"):
         assert np.array_equal(results[name].view(np.uint32), results["legacy"].view(np.uint32)), name
     moved = np.abs(results["legacy"][:3] - start.cpu().numpy()[:3, :n]).max()
