@@ -130,8 +130,8 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   int rc = ctx->kf_table.reserve(bytes);
   if (rc) return rc;
   const size_t rec_per_kf = (size_t)c.width * c.height;
-  if ((rc = ctx->records.reserve(table.size() * rec_per_kf * sizeof(uint2)))) return rc;
-  for (size_t k = 0; k < table.size(); ++k) table[k].records = (const uint2*)ctx->records.ptr + k * rec_per_kf;
+  if ((rc = ctx->records.reserve(table.size() * rec_per_kf * sizeof(PixelRecord)))) return rc;
+  for (size_t k = 0; k < table.size(); ++k) table[k].records = (const PixelRecord*)ctx->records.ptr + k * rec_per_kf;
   const bool with_color = !table.empty() && table[0].color != nullptr;
   const size_t quads_per_kf = (size_t)(c.color_width + 1) * (size_t)(c.color_height + 1);
   if (with_color) {
@@ -168,7 +168,7 @@ static int upload_kf_table(bslam_context* ctx, hipStream_t stream, std::vector<K
   }
   if (rebuild_records && !table.empty() && table[0].depth != nullptr) {
     hipLaunchKernelGGL(build_records_kernel, dim3((unsigned)((c.width + 255) / 256), (unsigned)c.height, (unsigned)table.size()), dim3(256), 0, stream,
-                       c, (const KfDev*)ctx->kf_table.ptr, (uint2*)ctx->records.ptr);
+                       c, (const KfDev*)ctx->kf_table.ptr, (PixelRecord*)ctx->records.ptr);
     BSLAM_HIP_TRY(hipGetLastError());
   }
   if (rebuild_quads) {

@@ -113,7 +113,7 @@ struct bslam_context {
   int tex_mode = BSLAM_TEX_FIXED_POINT_1_8;
   int cu_count = 256;
   bslam::Slab kf_table;      // KfDev[K]
-  bslam::Slab records;       // uint2[K][h][w] derived pixel records
+  bslam::Slab records;       // PixelRecord[K][h][w] derived pixel records (16 B)
   bslam::Slab quads;         // uint32[K][ch+1][cw+1] derived luma quads (only when colour images are given)
   bslam::Slab partials;      // float[tiles][K][32]
   bslam::Slab coeffs;        // float[K][32]

@@ -69,15 +69,17 @@ struct CamConsts {
   int tex_mode;
 };
 
+struct __attribute__((aligned(16))) PixelRecord { float depth, nx, ny, nz; };
+
 // Device view of one keyframe (pointers + pose), kept in a device array and read with scalar loads.
 struct KfDev {
   const uint8_t* depth;    uint32_t depth_pitch;
   const uint8_t* normals;  uint32_t normals_pitch;
   const uint8_t* color;    uint32_t color_pitch;
   const uint8_t* radius;   uint32_t radius_pitch;   // half radius^2 image (only the surfel lifecycle reads it)
-  // derived per-pixel records {f32 calibrated depth, u16 pixel normal, u16 raw depth}, row pitch in
+  // derived per-pixel records {f32 calibrated depth (0: no measurement), decoded pixel normal x, y, z}, row pitch in
   // records = image width (library-owned, rebuilt by build_records_kernel)
-  const uint2* records;
+  const PixelRecord* records;
   // derived luma quads: quads[(j + 1) * (color_width + 1) + (i + 1)] packs the 2x2 texel footprint
   // {L(i,j), L(i+1,j), L(i,j+1), L(i+1,j+1)} (clamp addressing, i in [-1, w-1], j in [-1, h-1]) so that a
   // bilinear sample is ONE 4-byte gather instead of four byte gathers (library-owned, build_quads_kernel)
@@ -269,6 +271,11 @@ __device__ __forceinline__ T gload(const T* p) {
 __device__ __forceinline__ uint2 gload_u2(const uint2* p) {   // one 8-byte load
   const unsigned long long v = gload((const unsigned long long*)p);
   return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ PixelRecord gload_record(const PixelRecord* p) {   // one 16-byte load
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = gload((const v4f*)p);
+  return PixelRecord{v.x, v.y, v.z, v.w};
 }
 
 struct LumaQuad { float tl, tr, bl, br; };   // texels (i,j), (i+1,j), (i,j+1), (i+1,j+1) in [0,1]
@@ -476,15 +483,16 @@ struct Proj {
   int px, py;
   float nx, ny;    // normalised image coordinates of the pixel centre (nx_of / ny_of), formed once per pair
   f2 pxy;
-  uint32_t pixel_normal;  // raw u16 normal of the associated pixel
-  uint32_t raw_depth;     // raw u16 depth of the associated pixel
+  f3 pixel_normal;        // decoded image-space normal of the associated pixel
 };
 
-// One derived record per pixel: the calibrated depth depends only on the pixel (raw depth, cfactor
-// cell, a), so its two IEEE divisions (+ expf) are paid once per pixel per call instead of once per
-// (surfel, keyframe) pair, and depth + pixel normal arrive in a single 8-byte gather.
-// Same arithmetic as RawToCalibratedDepth (BS/util.cuh:46-53), hence bit-identical depths.
-__global__ __launch_bounds__(256) void build_records_kernel(CamConsts c, const KfDev* __restrict__ kfs, uint2* __restrict__ records) {
+// One derived record per pixel: the calibrated depth depends only on the pixel (raw depth, cfactor cell, a) and the decoded
+// normal only on its u16 code, so the two IEEE divisions + expf of RawToCalibratedDepth (BS/util.cuh:46-53) and the sqrt of
+// U16ToImageSpaceNormal (BS/util.cuh:107-130) are paid once per pixel per call instead of once per (surfel, keyframe) pair
+// (~40 VALU instructions), and everything arrives in ONE 16-byte gather.  Same arithmetic, hence bit-identical values; a pixel
+// without measurement has depth 0, which the association test rejects like the reference's invalid bit (a valid raw depth
+// of 0 calibrates to 0 as well and fails the depth comparison either way).
+__global__ __launch_bounds__(256) void build_records_kernel(CamConsts c, const KfDev* __restrict__ kfs, PixelRecord* __restrict__ records) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   const int k = blockIdx.z;
@@ -497,7 +505,8 @@ __global__ __launch_bounds__(256) void build_records_kernel(CamConsts c, const K
     const float cf = *(const float*)((const uint8_t*)c.cfactor + (size_t)(y / c.cell) * c.cfactor_pitch + 4 * (size_t)(x / c.cell));
     depth = raw_to_calibrated_depth(c.a, cf, c.raw_to_float_depth, measured);
   }
-  records[((size_t)k * c.height + y) * c.width + x] = make_uint2(__float_as_uint(depth), normal | (measured << 16));
+  const f3 n = u16_to_image_space_normal(normal);
+  records[((size_t)k * c.height + y) * c.width + x] = PixelRecord{depth, n.x, n.y, n.z};
 }
 
 // Luma quads of every keyframe's colour image (see KfDev::quads); grid (ceil((w+1)/256), h+1, K).
@@ -534,16 +543,19 @@ __device__ __forceinline__ bool project_to_pixel(const CamConsts& c, const KfDev
 }
 // Stage 2: the pixel's derived record.  The offset inside one keyframe's table fits 24 bits (v_mad_u32_u24, full rate) and is
 // added to the uniform base as a 32-bit offset (global_load with an SGPR base): no 64-bit vector arithmetic per gather.
-__device__ __forceinline__ uint2 load_record(const CamConsts& c, const KfDev& kf, const Proj& r) {
+__device__ __forceinline__ PixelRecord load_record(const CamConsts& c, const KfDev& kf, const Proj& r) {
   const uint32_t idx = __umul24((uint32_t)r.py, (uint32_t)c.width) + (uint32_t)r.px;
-  return gload_u2(kf.records + idx);
+  return gload_record(kf.records + idx);
+}
+// raw u16 depth of the associated pixel (only the depth-intrinsics Jacobians need it)
+__device__ __forceinline__ uint32_t raw_depth_of(const KfDev& kf, const Proj& r) {
+  return gload((const uint16_t*)(kf.depth + (size_t)r.py * kf.depth_pitch + 2 * (size_t)r.px));
 }
 // Stage 3: IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127 on the loaded record.
-__device__ __forceinline__ bool associate_with_record(const CamConsts& c, const KfDev& kf, f3 gn, uint2 rec, Proj* r) {
+__device__ __forceinline__ bool associate_with_record(const CamConsts& c, const KfDev& kf, f3 gn, PixelRecord rec, Proj* r) {
   const M34& T = kf.frame_T_global;
-  if (rec.y & ((uint32_t)BSLAM_INVALID_DEPTH_BIT << 16)) return false;
-  r->depth = __uint_as_float(rec.x);
-  r->raw_depth = rec.y >> 16;
+  if (rec.depth == 0.f) return false;
+  r->depth = rec.depth;
   r->n_local = rot34(T, gn);
   r->nx = nx_of(c, (float)r->px);
   r->ny = ny_of(c, (float)r->py);
@@ -554,9 +566,8 @@ __device__ __forceinline__ bool associate_with_record(const CamConsts& c, const 
   // product has the sign of the dot product unless it underflows, which needs |dot| < 2^-23 * 2^-126 * |local|:
   // the sign test is evaluated on the dot product directly (saves a sqrt and a division per pair).
   if (dot(r->local, r->n_local) > 0) return false;
-  r->pixel_normal = rec.y & 0xffffu;
-  const f3 pn = u16_to_image_space_normal(r->pixel_normal);
-  if (dot(r->n_local, pn) < kCosNormalCompat) return false;
+  r->pixel_normal = mk3(rec.nx, rec.ny, rec.nz);
+  if (dot(r->n_local, r->pixel_normal) < kCosNormalCompat) return false;
   return true;
 }
 // gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
       if (kf.activation == BSLAM_KF_INACTIVE) continue;
       Proj p;
       if (!project_and_associate(c, kf, gp, gn, &p)) continue;
-      const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+      const f3 ln = p.pixel_normal;
       const float* R = kf.global_R_frame;
       sx += rot_row(R[0], R[1], R[2], ln);
       sy += rot_row(R[3], R[4], R[5], ln);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
       for (int r = 0; r < R; ++r) {
         Proj p;
         if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
-        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        const f3 ln = p.pixel_normal;
         sx[r] += rot_row(Rm[0], Rm[1], Rm[2], ln);
         sy[r] += rot_row(Rm[3], Rm[4], Rm[5], ln);
         sz[r] += rot_row(Rm[6], Rm[7], Rm[8], ln);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
       Proj p;
       if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       if (kPass == 0) {
-        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        const f3 ln = p.pixel_normal;
         a0[r] += rot_row(Rm[0], Rm[1], Rm[2], ln);
         a1[r] += rot_row(Rm[3], Rm[4], Rm[5], ln);
         a2[r] += rot_row(Rm[6], Rm[7], Rm[8], ln);
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         // the three quad gathers of the descriptor samples do not depend on the pixel record: issued with the record gather,
         // before the association test (see pose_accumulate_kernel)
         if (!on[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
-        const uint2 rec = load_record(c, kf, p);
+        const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
         project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         if (!on[r] || !project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
       }
       if constexpr (kPass == 0) {
-        const f3 ln = u16_to_image_space_normal(p.pixel_normal);
+        const f3 ln = p.pixel_normal;
         a[r][0] += rot_row(Rm[0], Rm[1], Rm[2], ln);
         a[r][1] += rot_row(Rm[3], Rm[4], Rm[5], ln);
         a[r][2] += rot_row(Rm[6], Rm[7], Rm[8], ln);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         // the quad gathers of the descriptor samples are issued with the record gather, before the association test
         // (see pose_accumulate_kernel)
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
-        const uint2 rec = load_record(c, kf, p);
+        const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
         tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
       if (kDepthIntr) {                                           // BS/kernel_opt_intrinsics.cu:82-118, 170-196
         const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
         const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
-        const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)p.raw_depth);
+        const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)raw_depth_of(kf, p));
         const f3 ln = p.n_local;
         const float inv_stddev = depth_inv_stddev(nx, ny, p.depth, ln, c.baseline_fx);
         float dj[6];

@@ -89,9 +89,9 @@ __device__ __forceinline__ bool associate_records_fs(const CamConsts& c, const K
   *px = f2i(pxy.x);
   *py = f2i(pxy.y);
   if (pxy.x < 0 || pxy.y < 0 || *px >= c.width || *py >= c.height) return false;
-  const uint2 rec = gload_u2(kf.records + ((size_t)*py * c.width + *px));
-  if (rec.y & ((uint32_t)BSLAM_INVALID_DEPTH_BIT << 16)) return false;
-  return association_tail<true>(c, local, rot34(T, gn), *px, *py, __uint_as_float(rec.x), rec.y & 0xffffu, fsv);
+  const PixelRecord rec = gload_record(kf.records + ((size_t)*py * c.width + *px));
+  if (rec.depth == 0.f) return false;
+  return association_tail<true>(c, local, rot34(T, gn), *px, *py, rec.depth, img_u16(kf.normals, kf.normals_pitch, *py, *px), fsv);
 }
 
 struct SurfelRowsAll {   // the eight persistent rows, writable

@@ -89,7 +89,7 @@ __device__ __forceinline__ DepthIntrinsicsTerms depth_intrinsics_terms(const Cam
   DepthIntrinsicsTerms t;
   const int sparse_px = p.px / c.cell, sparse_py = p.py / c.cell;
   const float cfactor = *(const float*)((const uint8_t*)c.cfactor + (size_t)sparse_py * c.cfactor_pitch + 4 * (size_t)sparse_px);
-  const uint32_t measured = p.raw_depth;
+  const uint32_t measured = raw_depth_of(kf, p);
   const float raw_inv_depth = 1.0f / (c.raw_to_float_depth * (float)measured);
   const float nx = nx_of(c, (float)p.px), ny = ny_of(c, (float)p.py);
   float dj[6];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       bool has_desc = false;
       if constexpr (kDesc) {
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
-        const uint2 rec = load_record(c, kf, p);
+        const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
         ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       bool has_desc = false;
       if constexpr (kDesc) {
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
-        const uint2 rec = load_record(c, kf, p);
+        const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
         ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),

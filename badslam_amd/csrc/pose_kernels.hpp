@@ -96,6 +96,12 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   const int kf_end = min(kf_count, kf_begin + kfs_per_block);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (states != nullptr) {
+    // late Gauss-Newton iterations: most keyframe chunks have nothing left to do; leave before touching the surfels
+    bool any = false;   // uniform
+    for (int k = kf_begin; k < kf_end; ++k) any = any || !states[k].converged;
+    if (!any) return;
+  }
 
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
         // flight (551 -> 517 us at K = 50).  Issued unconditionally -- the quad table's clamp addressing makes every address
         // valid -- so that no control-flow join sits in front of the record's wait (s_waitcnt vmcnt(3), not vmcnt(0)).
         if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) continue;
-        const uint2 rec = load_record(c, kf, p);
+        const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
         project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
