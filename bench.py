@@ -57,19 +57,6 @@ class Env:
     pass
 
 
-def morton_order(xyz, dims):
-    """Permutation that sorts points by the Morton code of their quantised coordinates (dims = 2: x, y only)."""
-    q = []
-    for d in range(dims):
-        v = xyz[d].astype(np.float64)
-        q.append(np.clip((v - v.min()) / max(1e-30, v.max() - v.min()) * 1023.0, 0, 1023).astype(np.uint64))
-    key = np.zeros(xyz.shape[1], np.uint64)
-    for bit in range(10):
-        for d in range(dims):
-            key |= ((q[d] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(bit * dims + d)
-    return np.argsort(key, kind="stable")
-
-
 def measure(env, K, use_desc, steps, warmup, stack=None):
     """Times `steps` BA iterations on a synthetic stack of K keyframes; returns the result dict of that workload."""
     import torch
@@ -82,8 +69,6 @@ def measure(env, K, use_desc, steps, warmup, stack=None):
     if world > 1:   # every rank builds the same keyframe stack; rank r jitters its surfel shard differently (weak scaling)
         rng = np.random.default_rng(1000 + rank)
         stack.surfels[2] += rng.uniform(-0.001, 0.001, stack.surfels_size).astype(np.float32)
-    if os.environ.get("BSLAM_BENCH_PERMUTE"):   # tuning runs only: surfel columns in per-surfel Morton order instead of creation order
-        stack.surfels = np.ascontiguousarray(stack.surfels[:, morton_order(stack.surfels[:3], int(os.environ["BSLAM_BENCH_PERMUTE"]))])
     dev = synthetic.DeviceStack(stack, device)
     S = dev.surfels_size
     badslam_amd.check(L.bslam_invalidate_keyframe_cache(ctx.handle))
