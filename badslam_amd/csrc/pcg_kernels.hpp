@@ -33,7 +33,12 @@ constexpr int kPcgThreads = 256;
 #define BSLAM_PCG_STEP1_WAVES_DESC 3
 #endif
 constexpr int kPcgR = BSLAM_PCG_R;
-constexpr int kPcgTile = kPcgThreads * kPcgR;
+#ifndef BSLAM_PCG_R_GEO
+#define BSLAM_PCG_R_GEO 3
+#endif
+// surfels per thread: the geometry-only kernels without intrinsics are light on registers and amortise the per-keyframe
+// reduction (6 - 12 wave sums + a barrier) over twice as many pairs
+constexpr int pcg_surfels_per_thread(bool desc, bool intr) { return (!desc && !intr) ? BSLAM_PCG_R_GEO : kPcgR; }
 constexpr int kPcgPoseRow = 12;    // init: r[6], M[6];  step1: g[6] (+6 unused)
 constexpr int kPcgGlobRow = 20;    // init: depth intr r[5], M[5], colour r[4], M[4]; step1: alpha_d, g depth[5], g colour[4]
 
@@ -139,6 +144,7 @@ template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  constexpr int R = pcg_surfels_per_thread(kDesc, kIntr);
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
@@ -146,14 +152,14 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   __shared__ float red[2][4][16];
   __shared__ float redg[4][32];
 
-  f3 gp[kPcgR], gn[kPcgR];
-  bool valid[kPcgR];
-  uint32_t idx[kPcgR];
-  __shared__ float state[kDesc ? kPcgStateComps * kPcgR * kPcgThreads : 1];
-  float ar[kPcgR][3], aM[kPcgR][3];
+  f3 gp[R], gn[R];
+  bool valid[R];
+  uint32_t idx[R];
+  __shared__ float state[kDesc ? kPcgStateComps * R * kPcgThreads : 1];
+  float ar[R][3], aM[R][3];
 #pragma unroll
-  for (int r = 0; r < kPcgR; ++r) {
-    const uint32_t i = surfel_of_slot(sc, slot, r, kPcgR);
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = surfel_of_slot(sc, slot, r, R);
     valid[r] = i < s.size;
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
     for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = 0.f;
 
 #pragma unroll
-    for (int r = 0; r < kPcgR; ++r) {
+    for (int r = 0; r < R; ++r) {
       Proj p;
       DescSamples ds;
       bool has_desc = false;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 
   if (P.optimize_geometry) {
 #pragma unroll
-    for (int r = 0; r < kPcgR; ++r) {
+    for (int r = 0; r < R; ++r) {
       if (!valid[r]) continue;
       const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * (P.perm ? P.perm[idx[r]] : idx[r]);
       P.r[base] = ar[r][0];
@@ -397,6 +403,7 @@ template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_PCG_STEP1_WAVES_DESC : 4))) void pcg_step1_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  constexpr int R = pcg_surfels_per_thread(kDesc, kIntr);
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
@@ -404,14 +411,14 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   __shared__ float red[2][4][16];
   __shared__ float redg[4][32];
 
-  f3 gp[kPcgR], gn[kPcgR];
-  bool valid[kPcgR];
-  uint32_t idx[kPcgR];
-  __shared__ float state[kDesc ? kPcgStateComps * kPcgR * kPcgThreads : 1];
-  float ps[kPcgR][3], ag[kPcgR][3];
+  f3 gp[R], gn[R];
+  bool valid[R];
+  uint32_t idx[R];
+  __shared__ float state[kDesc ? kPcgStateComps * R * kPcgThreads : 1];
+  float ps[R][3], ag[R][3];
 #pragma unroll
-  for (int r = 0; r < kPcgR; ++r) {
-    const uint32_t i = surfel_of_slot(sc, slot, r, kPcgR);
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = surfel_of_slot(sc, slot, r, R);
     valid[r] = i < s.size;
     idx[r] = valid[r] ? i : 0;
     gp[r] = mk3(s.x[idx[r]], s.y[idx[r]], s.z[idx[r]]);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
     for (int i = 0; i < 6; ++i) pose[i] = 0.f;
 
 #pragma unroll
-    for (int r = 0; r < kPcgR; ++r) {
+    for (int r = 0; r < R; ++r) {
       Proj p;
       DescSamples ds;
       bool has_desc = false;
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
 
   if (P.optimize_geometry) {
 #pragma unroll
-    for (int r = 0; r < kPcgR; ++r) {
+    for (int r = 0; r < R; ++r) {
       if (!valid[r]) continue;
       const uint32_t base = P.surfel_start + (uint32_t)P.per_surfel * (P.perm ? P.perm[idx[r]] : idx[r]);
       P.g[base] = ag[r][0];
