@@ -500,3 +500,29 @@ def test_photometric_geometry_chunked_equals_single_launch(oracle):
     assert np.array_equal(got[3].view(np.uint32), scene.surfels[3, :n].view(np.uint32))      # packed normals: bit-exact
     assert np.abs(got[:3] - scene.surfels[:3, :n]).max() < 1e-5
     assert np.abs(got[6:8] - scene.surfels[6:8, :n]).max() < 2e-3    # descriptors (range +-180)
+
+
+def test_per_surfel_work_order_is_transparent(multi):
+    """Calls with >= 4 keyframes walk the surfels in the library's own order (Morton order of the positions, on a sorted copy of
+    the rows, include/badslam_hip.h: bslam_set_xcd_schedule).  What is computed per surfel must not depend on it at all --
+    activation flags, normals, positions, descriptors: identical bits with and without -- and the per-keyframe sums only in
+    their summation order."""
+    scene, hip = multi
+    assert scene.surfels_size >= 64 * 256 and len(scene.keyframes) >= 4          # large enough for the order to be used
+    start = hip.d.surfels.clone()
+    out = {}
+    for enable in (1, 0):
+        badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, enable))
+        hip.d.surfels.copy_(start)
+        hip.update_activation()
+        hip.optimize_geometry_iteration()
+        Hb, counts = hip.accumulate_pose_batched()
+        out[enable] = (hip.d.active_np()[0, :scene.surfels_size].copy(), hip.d.surfels_np()[:8, :scene.surfels_size].copy(), Hb, counts)
+    badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, 1))
+    hip.d.surfels.copy_(start)
+    assert np.array_equal(out[1][0], out[0][0])
+    assert np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32))
+    assert np.abs(out[1][1][:3] - start.cpu().numpy()[:3, :scene.surfels_size]).max() > 1e-6    # the iteration moved the surfels
+    assert np.array_equal(out[1][3], out[0][3])
+    for k in range(len(scene.keyframes)):
+        assert rel_close(out[1][2][k, :21], out[0][2][k, :21], rel=1e-5), k
