@@ -69,6 +69,9 @@ struct CamConsts {
   int tex_mode;
 };
 
+#ifndef BSLAM_PROJECT_SINGLE_BRANCH
+#define BSLAM_PROJECT_SINGLE_BRANCH 1
+#endif
 #ifndef BSLAM_ASSOC_SINGLE_BRANCH
 #define BSLAM_ASSOC_SINGLE_BRANCH 1
 #endif
@@ -536,13 +539,20 @@ __global__ __launch_bounds__(256) void build_quads_kernel(CamConsts c, const KfD
 __device__ __forceinline__ bool project_to_pixel(const CamConsts& c, const KfDev& kf, f3 gp, Proj* r) {
   const M34& T = kf.frame_T_global;
   r->local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
+#if !BSLAM_PROJECT_SINGLE_BRANCH
   if (r->local.z <= 0.f) return false;
+#endif
   r->local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
   r->local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
   r->pxy = project(c.fx, c.fy, c.cx, c.cy, r->local);
   r->px = f2i(r->pxy.x);
   r->py = f2i(r->pxy.y);
+#if BSLAM_PROJECT_SINGLE_BRANCH
+  // one exit: a point behind the camera projects to garbage (finite or not) that the z test discards
+  return (r->local.z > 0.f) & !(r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height);
+#else
   return !(r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height);
+#endif
 }
 // Stage 2: the pixel's derived record.  The offset inside one keyframe's table fits 24 bits (v_mad_u32_u24, full rate) and is
 // added to the uniform base as a 32-bit offset (global_load with an SGPR base): no 64-bit vector arithmetic per gather.
