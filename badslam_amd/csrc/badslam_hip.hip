@@ -386,7 +386,7 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   SurfelWork local;
   int rc = BSLAM_OK;
   if (!work) {
-    if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_desc ? kPoseRDesc : kPoseRGeo, kf_count, &local, use_desc != 0))) return rc;
+    if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, pose_surfels_per_thread(use_desc != 0, surfels_size), kf_count, &local, use_desc != 0))) return rc;
     work = &local;
   }
   const Schedule sc = work->sc;
@@ -409,6 +409,7 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   {
   ProfScope prof(ctx, stream);
   if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeoLarge>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
   }
@@ -850,7 +851,7 @@ int bslam_estimate_frame_poses_batched(
   BSLAM_HIP_TRY(hipGetLastError());
 
   SurfelWork work;   // schedule + (sorted) surfel rows: the surfels do not change during the loop
-  if (surfels_size > 0 && (rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? kPoseRDesc : kPoseRGeo, keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
+  if (surfels_size > 0 && (rc = prepare_surfels(ctx, stream, surfels, surfels_size, pose_surfels_per_thread(use_descriptor_residuals != 0, surfels_size), keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
 
   // One Gauss-Newton iteration of all unconverged keyframes, ending with the number of keyframes still
   // unconverged on its way to h_active[it % 4].

@@ -34,6 +34,16 @@ constexpr int kPoseThreads = 256;
 #endif
 constexpr int kPoseRGeo = BSLAM_POSE_R_GEO;
 constexpr int kPoseRDesc = BSLAM_POSE_R_DESC;
+// Large geometry-only problems amortise the per-keyframe wave reduction over 6 surfels per thread at 5 waves per SIMD (K = 200,
+// S = 3.84 M: 1256 -> 1200 us per launch); small ones need the blocks (K = 50, S = 0.96 M: 97.5 us with 4, 98.3 with 6).
+#ifndef BSLAM_POSE_R_GEO_LARGE
+#define BSLAM_POSE_R_GEO_LARGE 6
+#endif
+constexpr int kPoseRGeoLarge = BSLAM_POSE_R_GEO_LARGE;
+constexpr uint32_t kPoseLargeSurfels = 2000000u;
+inline int pose_surfels_per_thread(bool use_desc, uint32_t surfels_size) {
+  return use_desc ? kPoseRDesc : (surfels_size >= kPoseLargeSurfels ? kPoseRGeoLarge : kPoseRGeo);
+}
 constexpr int kRow = 32;                       // floats per partial row: 21 H, 6 b, cost, count bits, pad
 constexpr int kRowCost = 27;
 constexpr int kRowCount = 28;
@@ -80,7 +90,7 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 #ifndef BSLAM_POSE_WAVES_DESC
 #define BSLAM_POSE_WAVES_DESC 5
 #endif
-#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : BSLAM_POSE_WAVES_GEO)))
+#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : (kPoseR > 4 ? 5 : BSLAM_POSE_WAVES_GEO))))
 template <bool kDepth, bool kDesc, int kPoseR>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
