@@ -324,6 +324,8 @@ def geometry_roofline(S, K, frac_inb, use_desc, steps, active_surfel_steps, tota
     nbytes = pairs * (frac_inb * B_NORMALS + (1 - frac_inb) * B_REJECTED) + pairs * (frac_inb * B_POSITION[use_desc] + (1 - frac_inb) * B_REJECTED)
     per_step_s = total_ms / 1e3 / steps
     ach = nbytes / per_step_s / 1e9
+    # same convention as the dominant kernel: ALGORITHMIC gather bytes against the HBM peak.  With the per-surfel work order most
+    # of those gathers are served by L1 / L2 (see traffic), so the fraction can pass 1: it is not a physical utilisation.
     return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "us_per_step": per_step_s * 1e6, "algorithmic_bytes_per_step": nbytes,
             "traffic": pmc_value(pmc, "geometry_kernel", "hbm_bytes"), "traffic_raw": pmc_value(pmc, "geometry_kernel", "hbm_bytes_raw")}
 
