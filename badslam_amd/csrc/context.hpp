@@ -132,7 +132,7 @@ struct bslam_context {
   bool keyframe_cache = false;
   std::vector<uint64_t> records_signature;   // what the depth records were built from
   std::vector<uint64_t> quads_signature;     // what the luma quads were built from
-  // XCD-aware schedule (granule order), cached per surfel buffer
+  // XCD-aware schedule: granule order (short keyframe lists) and per-surfel order, each cached per surfel buffer
   bslam::Slab quads_aux;     // luma quads of the tracked frame's colour pyramid level (odometry)
   bslam::Slab lifecycle;     // supporting-surfel cell images, scan buffers, flags of the surfel lifecycle calls
   bslam::Slab exchange;      // staging of the multi-rank exchanges (PCG shared unknowns, intrinsics sums)

@@ -445,13 +445,10 @@ __global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev*
   }
 }
 
-// kMode 1 with R surfels (granules) per thread, interleaved keyframe by keyframe.  With R = 2 the whole grid
-// (ceil(S / 512) workgroups) is resident at once on 256 CUs for S <= 1M, so all workgroups walk the keyframe
-// table in near lockstep and the XCD's L2 serves the records of the few keyframes in flight (a grid that needs a
-// second round of workgroups runs two phases of the table at once).  Per-surfel sums are still formed in keyframe
-// order: same bits as the R = 1 kernel.
-// Larger surfel counts are covered by several launches of at most one resident grid each (first_i = first slot of every
-// XCD's range handled by this launch).
+// kMode 1 with R surfels per thread, interleaved keyframe by keyframe: R independent gather chains per thread, per-surfel sums
+// formed in keyframe order (same bits as the R = 1 kernel).  One launch covers all surfels (first_i = 0); round 1 launched it
+// one resident grid at a time to keep the workgroups in lockstep on the keyframe table, which the per-surfel work order made
+// unnecessary (first_i = first slot of every XCD's range handled by a launch is kept for that use).
 template <int R>
 __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, uint32_t first_i,
                                                                SurfelRowsRW s) {
@@ -529,9 +526,9 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
 }
 
 // The same two passes for long keyframe lists, one launch per chunk of keyframes: the per-surfel sums travel between the
-// launches in library scratch (acc: 4 floats per surfel), so the workgroups of a resident grid re-align at every chunk
-// boundary instead of drifting apart over hundreds of keyframes.  Sums are still formed in keyframe order: same bits as
-// the single-launch kernel.  pass 0: normals (acc = sx, sy, sz, count), pass 1: position (acc = H, b).
+// launches in library scratch (acc: 4 floats per surfel).  Sums are still formed in keyframe order: same bits as the
+// single-launch kernel.  (Selected by bslam_set_geometry_keyframe_chunk; the default since the per-surfel work order is one
+// launch over the whole list.)  pass 0: normals (acc = sx, sy, sz, count), pass 1: position (acc = H, b).
 template <int R, int kPass>
 __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
                                                             Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
@@ -602,7 +599,7 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
 }
 
 // The joint position + descriptor iteration (kMode 2 of geometry_kernel) in the same launch shape as geometry_chunk_kernel: R surfels
-// per thread walked keyframe by keyframe, one resident grid per launch, the keyframe list cut into chunks whose per-surfel sums
+// per thread walked keyframe by keyframe, the keyframe list optionally cut into chunks whose per-surfel sums
 // travel in library scratch (acc: 4 floats per surfel for the normals pass, 8 for the joint pass).  Sums are formed in keyframe
 // order: same bits as geometry_kernel<2, kDepth>.  kPass 0: normals (= geometry_chunk_kernel's pass 0, repeated here so that a
 // photometric iteration needs no geometry-only instantiation of a different R); kPass 1: position + descriptors

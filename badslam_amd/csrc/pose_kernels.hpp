@@ -6,9 +6,11 @@
 //
 // MI355X design (not the reference's one-launch-per-keyframe, 27-block-reductions-per-launch
 // shape):
-//   * one launch covers (surfel tiles) x (keyframe chunks); a thread keeps kR surfels in
-//     registers (position + decoded normal) and walks the keyframes of its chunk, so surfel
-//     bytes are read once per chunk instead of once per keyframe;
+//   * one launch covers (surfel tiles) x (keyframe chunks); a thread keeps kR surfels (position +
+//     decoded normal in registers; the photometric variant's 14 per-surfel constants in LDS) and
+//     walks the keyframes of its chunk, so surfel bytes are read once per chunk instead of once
+//     per keyframe; the surfels come in the library's per-surfel Morton order (sorted copy of the
+//     rows, badslam_hip.hip: prepare_surfels), so a wave's 64 surfels are a compact blob;
 //   * the 21 + 6 (+ cost, count) coefficients are accumulated per thread over its kR surfels
 //     (fused multiply-adds: these sums are compared at 1e-4, only the association predicates
 //     need bit-exact arithmetic), reduced across the wave with a transposing butterfly
