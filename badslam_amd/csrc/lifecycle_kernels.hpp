@@ -368,9 +368,15 @@ __global__ __launch_bounds__(256) void create_append_kernel(CamConsts c, KfImage
 // ---------------------------------------------------------------------------------------------
 // deletion + radius update: BS/kernel_delete_surfels.cu (reset + K count launches + mark, fused)
 // ---------------------------------------------------------------------------------------------
+// Work order as in the BA kernels (make_schedule): block -> slot of an XCD-contiguous range, position -> surfel column through
+// the per-surfel Morton permutation `perm` (nullptr: identity).  K = 300, S = 5.76 M: 30.7 ms -> about 5 ms (PCG BA iteration 370 -> 344 ms).
 __global__ __launch_bounds__(256) void delete_and_update_radii_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int min_observation_count,
-                                                                     uint32_t size, SurfelRowsAll s, uint32_t* __restrict__ deleted_count) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                                     uint32_t size, Schedule sc, const uint32_t* __restrict__ perm, SurfelRowsAll s,
+                                                                     uint32_t* __restrict__ deleted_count) {
+  uint32_t slot;
+  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
+  const uint32_t at = surfel_of_slot(sc, slot, 0, 1);
+  const uint32_t i = (perm != nullptr && at < size) ? perm[at] : at;
   bool deleted = false;
   if (i < size) {
     const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
