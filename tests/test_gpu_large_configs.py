@@ -56,12 +56,12 @@ class Runner:
         self.torch.cuda.synchronize()
 
 
-def check_additive_and_deterministic(run, rel):
+def check_additive_and_deterministic(run, rel, cut=None):
     S = run.dev.surfels_size
     full, cnt = run.coeffs()
     again, cnt2 = run.coeffs()
     assert np.array_equal(full.view(np.uint32), again.view(np.uint32)) and np.array_equal(cnt, cnt2), "two runs must agree bit for bit"
-    cut = (S // 3) & ~255
+    cut = ((S // 3) & ~255) if cut is None else cut
     a, ca = run.coeffs(run.dev.surfels[:, :cut].contiguous())
     b, cb = run.coeffs(run.dev.surfels[:, cut:].contiguous())
     assert np.array_equal(ca.astype(np.uint64) + cb, cnt.astype(np.uint64)), "residual counts are integers: exactly additive over shards"
@@ -121,6 +121,9 @@ def test_configs4_geometry_1000_keyframes_20m_surfels_properties():
     assert int(act.sum()) > 0.99 * dev.surfels_size
     assert torch.equal(run.activation(), act)
     check_additive_and_deterministic(run, 1e-4)
+    # a shard below 2 M surfels runs the 4-surfels-per-thread pose kernel, the rest and the whole the 6-surfel one
+    # (csrc/pose_kernels.hpp: pose_surfels_per_thread): additivity across the two instantiations
+    check_additive_and_deterministic(run, 1e-4, cut=1500 * 1024)
     # geometry iteration: keyframe chunks of 128 vs one launch over the 1000 keyframes (default), bit-identical
     start = dev.surfels.clone()
     badslam_amd.check(run.L.bslam_set_geometry_keyframe_chunk(run.ctx.handle, 128))
