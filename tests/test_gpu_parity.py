@@ -526,3 +526,33 @@ def test_per_surfel_work_order_is_transparent(multi):
     assert np.array_equal(out[1][3], out[0][3])
     for k in range(len(scene.keyframes)):
         assert rel_close(out[1][2][k, :21], out[0][2][k, :21], rel=1e-5), k
+
+
+def test_work_order_with_deleted_surfels(multi):
+    """Deleted surfels (x = NaN, BS/kernel_delete_surfels.cu) stay in the buffer until compaction: they sort to the end of the work
+    order, are never associated, and are left untouched -- with the per-surfel order as without it."""
+    import torch
+    scene, hip = multi
+    start = hip.d.surfels.clone()
+    n = scene.surfels_size
+    dead = torch.arange(0, n, 17, device=hip.d.surfels.device)
+    out = {}
+    try:
+        for enable in (1, 0):
+            badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, enable))
+            hip.d.surfels.copy_(start)
+            hip.d.surfels[0, dead] = float("nan")
+            hip.update_activation()
+            hip.optimize_geometry_iteration()
+            Hb, counts = hip.accumulate_pose_batched()
+            out[enable] = (hip.d.active_np()[0, :n].copy(), hip.d.surfels_np()[:8, :n].copy(), Hb, counts)
+    finally:
+        badslam_amd.check(hip.L.bslam_set_xcd_schedule(hip.ctx.handle, 1))
+        hip.d.surfels.copy_(start)
+    dead = dead.cpu().numpy()
+    assert np.array_equal(out[1][0], out[0][0]) and not out[1][0][dead].any()                       # never activated
+    assert np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32))
+    assert np.isnan(out[1][1][0, dead]).all()
+    assert np.array_equal(out[1][1][1:, dead].view(np.uint32), start.cpu().numpy()[1:8, dead].view(np.uint32))   # untouched
+    assert np.array_equal(out[1][3], out[0][3]) and out[1][3].min() > 1000
+    assert np.isfinite(out[1][2]).all()
