@@ -556,3 +556,28 @@ def test_work_order_with_deleted_surfels(multi):
     assert np.array_equal(out[1][1][1:, dead].view(np.uint32), start.cpu().numpy()[1:8, dead].view(np.uint32))   # untouched
     assert np.array_equal(out[1][3], out[0][3]) and out[1][3].min() > 1000
     assert np.isfinite(out[1][2]).all()
+
+
+def test_photometric_gauss_newton_converges_alike_in_both_texture_modes(oracle):
+    """The batched photometric pose loop from 5 mm / 1 mrad perturbations: converged flags set well inside the cap of 30
+    (BS/direct_ba_alternating.cc:130), the rendered poses recovered, and -- the 1/256 weight quantisation of the fixed-point
+    texture mode being the one unpinned piece of the sampling arithmetic -- the same iteration counts and the same poses to 1e-6
+    with exact float weights: the loop's convergence does not hinge on that guess."""
+    from badslam_amd import abi
+    from tests import gpu_util
+    results = {}
+    for name, mode in (("fixed", abi.TEX_FIXED_POINT_1_8), ("exact", abi.TEX_EXACT_FLOAT)):
+        scene = scenes.synthetic_scene(4, seed=5, use_depth_residuals=True, use_descriptor_residuals=True, tex_mode=mode)
+        hip = gpu_util.Hip(scene.to_device("cuda:0"))
+        rng = np.random.default_rng(1)
+        inits = [bso.se3_mul(kf.global_T_frame, bso.se3_exp(np.concatenate([rng.choice([-1, 1], 3) * 0.005, rng.choice([-1, 1], 3) * 0.001]).astype(np.float32)))
+                 for kf in scene.keyframes]
+        errs = []
+        for cap in (1, 2, 4, 30):
+            poses, iters, conv = hip.estimate_poses_batched(inits, max_iterations=cap)
+            errs.append(max(np.abs(pose_error(p, kf.global_T_frame)).max() for p, kf in zip(poses, scene.keyframes)))
+        assert all(conv) and max(iters) <= 10, (name, iters, conv)
+        assert errs[0] > errs[1] > errs[2] > errs[3] and errs[3] < 1e-4, (name, errs)
+        results[name] = (iters, np.stack([bso.se3_to_np(p) for p in poses]))
+    assert results["fixed"][0] == results["exact"][0]
+    assert np.abs(results["fixed"][1] - results["exact"][1]).max() < 1e-6
