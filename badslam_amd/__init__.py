@@ -80,6 +80,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(lib().bslam_comm_init(self._ctx, buf, rank, world_size))
 
+    def comm_query(self):
+        """(rank, world size) as the RCCL communicator reports them; (0, 1) without one."""
+        r, w = C.c_int(), C.c_int()
+        check(lib().bslam_comm_query(self._ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def comm_destroy(self):
         check(lib().bslam_comm_destroy(self._ctx))
 

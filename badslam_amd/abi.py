@@ -129,6 +129,7 @@ SIGNATURES = {
     "bslam_comm_get_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "bslam_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "bslam_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bslam_comm_query": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),
     "bslam_profile_read_counters": (C.c_int, [C.c_void_p, P(C.c_uint64)]),

@@ -237,6 +237,8 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
   if (!ctx->use_schedule || G < 64) return BSLAM_OK;   // tiny problems: identity order
   const bool want_perm = perm_out != nullptr && keyframe_count >= kPermMinKeyframes;
   if (want_perm && ctx->perm_key_ptr == surfels->address && ctx->perm_key_size == surfels_size && ctx->perm_key_pitch == surfels->pitch) {
+    // the permutation was sorted asynchronously on the stream of the call that built it: a call on another stream waits for it
+    if (stream != ctx->perm_stream && ctx->perm_ready) BSLAM_HIP_TRY(hipStreamWaitEvent(stream, ctx->perm_ready, 0));
     *perm_out = (const uint32_t*)ctx->perm.ptr;
     return BSLAM_OK;
   }
@@ -244,13 +246,11 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
     out->order = (const uint32_t*)ctx->order.ptr;
     return BSLAM_OK;
   }
-  int rc = ctx->order.reserve((size_t)G * sizeof(uint32_t) + (size_t)G * sizeof(float4));
+  // granule centroids live in their own slab: the per-surfel path below must not disturb the cached granule order
+  // (ctx->order) of another buffer, whose key stays valid
+  int rc = ctx->centroids.reserve((size_t)G * sizeof(float4));
   if (rc) return rc;
-  uint32_t* d_order = (uint32_t*)ctx->order.ptr;
-  float4* d_cent = (float4*)((uint8_t*)ctx->order.ptr + (((size_t)G * sizeof(uint32_t) + 15) / 16) * 16);
-  if ((rc = ctx->order.reserve((size_t)((uint8_t*)(d_cent + G) - (uint8_t*)ctx->order.ptr)))) return rc;
-  d_order = (uint32_t*)ctx->order.ptr;
-  d_cent = (float4*)((uint8_t*)ctx->order.ptr + (((size_t)G * sizeof(uint32_t) + 15) / 16) * 16);
+  float4* d_cent = (float4*)ctx->centroids.ptr;
   auto row = [&](int r) { return (const float*)((const uint8_t*)surfels->address + (size_t)r * surfels->pitch); };
   hipLaunchKernelGGL(granule_centroid_kernel, dim3(G), dim3(kGranule), 0, stream, row(BSLAM_SURFEL_X), row(BSLAM_SURFEL_Y), row(BSLAM_SURFEL_Z), surfels_size, d_cent);
   BSLAM_HIP_TRY(hipGetLastError());
@@ -267,6 +267,7 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
     // keys + identity -> radix sort by key -> perm.  Layout of ctx->perm: perm[S] | keys[S] | keys_sorted[S] | ids[S] | sort scratch
     const size_t n = surfels_size, words = (n + 63) & ~(size_t)63;
     size_t temp_bytes = 0;
+    ctx->perm_key_ptr = nullptr;   // as above
     BSLAM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 30, stream));
     if ((rc = ctx->perm.reserve(4 * words * sizeof(uint32_t) + temp_bytes + 256))) return rc;
     uint32_t* d_perm = (uint32_t*)ctx->perm.ptr;
@@ -282,12 +283,18 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
                        surfels_size, lo3, inv3, d_keys, d_ids);
     BSLAM_HIP_TRY(hipGetLastError());
     BSLAM_HIP_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, (const uint32_t*)d_keys, d_keys_sorted, (const uint32_t*)d_ids, d_perm, n, 0, 30, stream));
+    if (!ctx->perm_ready) BSLAM_HIP_TRY(hipEventCreateWithFlags(&ctx->perm_ready, hipEventDisableTiming));
+    BSLAM_HIP_TRY(hipEventRecord(ctx->perm_ready, stream));
+    ctx->perm_stream = stream;
     ctx->perm_key_ptr = surfels->address;
     ctx->perm_key_size = surfels_size;
     ctx->perm_key_pitch = surfels->pitch;
     *perm_out = d_perm;
     return BSLAM_OK;
   }
+  ctx->order_key_ptr = nullptr;   // the slab may move and is rewritten below: no stale key survives an early return
+  if ((rc = ctx->order.reserve((size_t)G * sizeof(uint32_t)))) return rc;
+  uint32_t* d_order = (uint32_t*)ctx->order.ptr;
   std::vector<std::pair<uint32_t, uint32_t>> keyed(G);
   for (uint32_t g = 0; g < G; ++g) {
     uint32_t key = 0x3fffffffu;   // empty granules last
@@ -432,12 +439,25 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
 namespace {
 using bslam::fail;
 struct RcclId128 { char b[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+constexpr int kRcclFloat32 = 7, kRcclSum = 0;
+}  // namespace
+// The prototypes below are declared by hand so that the library carries no build dependency on RCCL; where its header is
+// installed the assumptions are checked against it at compile time.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == sizeof(RcclId128), "ncclUniqueId is not 128 bytes");
+static_assert((int)ncclFloat32 == kRcclFloat32 && (int)ncclSum == kRcclSum, "RCCL enum values changed");
+static_assert(sizeof(ncclComm_t) == sizeof(void*), "ncclComm_t is not a pointer");
+#endif
+namespace {
 struct RcclApi {
   void* handle = nullptr;
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -452,6 +472,8 @@ int load_rccl() {
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+  g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
     dlclose(h);
     return fail(BSLAM_ERR_HIP, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
@@ -465,8 +487,8 @@ const char* rccl_error(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorSt
 namespace bslam {
 int rccl_allreduce_sum(bslam_context* ctx, hipStream_t stream, float* device_buffer, size_t count) {
   if (count == 0) return BSLAM_OK;
-  // ncclFloat32 = 7, ncclSum = 0 (rccl.h); in place, on the caller's stream: ordered after the producers the library enqueued
-  const int e = g_rccl.AllReduce(device_buffer, device_buffer, count, 7, 0, ctx->comm, stream);
+  // in place, on the caller's stream: ordered after the producers the library enqueued
+  const int e = g_rccl.AllReduce(device_buffer, device_buffer, count, kRcclFloat32, kRcclSum, ctx->comm, stream);
   if (e != 0) return fail(BSLAM_ERR_HIP, "ncclAllReduce(%zu floats) failed: %s", count, rccl_error(e));
   return BSLAM_OK;
 }
@@ -502,9 +524,10 @@ int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
   bslam_comm_destroy(ctx);
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->perm.release(); ctx->sorted_rows.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->centroids.release(); ctx->perm.release(); ctx->sorted_rows.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
+  if (ctx->perm_ready) { hipError_t err = hipEventDestroy(ctx->perm_ready); (void)err; ctx->perm_ready = nullptr; }
   for (auto& ev : ctx->prof_pending) ctx->prof_pool.push_back(std::make_pair(ev.start, ev.stop));
   for (auto& ev : ctx->prof_pool) { hipError_t e1 = hipEventDestroy(ev.first); e1 = hipEventDestroy(ev.second); (void)e1; }
   delete ctx;
@@ -549,6 +572,21 @@ int bslam_comm_init(bslam_context* ctx, const void* unique_id, int rank, int wor
   ctx->comm = comm;
   ctx->comm_rank = rank;
   ctx->comm_world = world_size;
+  return BSLAM_OK;
+}
+
+int bslam_comm_query(bslam_context* ctx, int* rank, int* world_size) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  int r = 0, w = 1;
+  if (ctx->comm) {
+    // read back from the communicator itself (ncclCommUserRank / ncclCommCount), not from what bslam_comm_init was told
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(BSLAM_ERR_HIP, "librccl lacks ncclCommCount / ncclCommUserRank");
+    int e = g_rccl.CommCount(ctx->comm, &w);
+    if (e == 0) e = g_rccl.CommUserRank(ctx->comm, &r);
+    if (e != 0) return fail(BSLAM_ERR_HIP, "ncclCommCount / ncclCommUserRank failed: %s", rccl_error(e));
+  }
+  if (rank) *rank = r;
+  if (world_size) *world_size = w;
   return BSLAM_OK;
 }
 
@@ -865,8 +903,11 @@ int bslam_estimate_frame_poses_batched(
       int tiles = 0;
       int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work);
       if (r) return r;
-      hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
-                         tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
+      {
+        ProfScope prof(ctx, stream, BSLAM_PROF_POSE_REDUCE);
+        hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
+                           tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
+      }
       BSLAM_HIP_TRY(hipGetLastError());
     } else {
       if (surfels_size > 0) {
@@ -878,13 +919,16 @@ int bslam_estimate_frame_poses_batched(
         if (r) return r;
         BSLAM_HIP_TRY(hipMemsetAsync(ctx->coeffs.ptr, 0, (size_t)keyframe_count * kRow * sizeof(float), stream));   // H.setZero(); b.setZero() (:147-149)
       }
-      if (allreduce) {
-        // rows of converged keyframes are zeros on every rank; the solve kernel ignores them.
-        const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
-        if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
-      } else if (exchange) {
-        const int arc = exchange_sum(ctx, stream, (float*)ctx->coeffs.ptr, (size_t)keyframe_count * kRow);
-        if (arc) return arc;
+      {
+        ProfScope prof(ctx, stream, BSLAM_PROF_EXCHANGE);
+        if (allreduce) {
+          // rows of converged keyframes are zeros on every rank; the solve kernel ignores them.
+          const int arc = allreduce(allreduce_user, ctx->coeffs.ptr, (size_t)keyframe_count * kRow, stream);
+          if (arc) return fail(BSLAM_ERR_HIP, "allreduce callback failed with %d", arc);
+        } else if (exchange) {
+          const int arc = exchange_sum(ctx, stream, (float*)ctx->coeffs.ptr, (size_t)keyframe_count * kRow);
+          if (arc) return arc;
+        }
       }
       hipLaunchKernelGGL(pose_solve_kernel, dim3((unsigned)((keyframe_count + 63) / 64)), dim3(64), 0, stream,
                          (const float*)ctx->coeffs.ptr, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));

@@ -141,11 +141,14 @@ struct bslam_context {
   void* comm = nullptr;                     // bslam_comm_init: RCCL communicator (ncclComm_t) of the surfel-sharded run
   int comm_rank = 0, comm_world = 1;
   bslam::Slab order;
+  bslam::Slab centroids;     // granule centroids (scratch of make_schedule)
   bslam::Slab perm;          // per-surfel Morton order (+ sort scratch), cached like `order`
   bslam::Slab sorted_rows;   // the seven persistent surfel rows in that order, rebuilt by every call that uses it
   const void* perm_key_ptr = nullptr;
   uint32_t perm_key_size = 0;
   size_t perm_key_pitch = 0;
+  hipEvent_t perm_ready = nullptr;   // recorded behind the sort that produced `perm`
+  hipStream_t perm_stream = nullptr; // ... on this stream
   bool use_schedule = true;
   const void* order_key_ptr = nullptr;
   uint32_t order_key_size = 0;

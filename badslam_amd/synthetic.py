@@ -94,24 +94,88 @@ def s10_pack(n):
     return s10(n[..., 0]) | (s10(n[..., 1]) << 10) | (s10(n[..., 2]) << 20)
 
 
-class SyntheticStack:
-    """Host arrays of a synthetic keyframe stack + surfel SoA."""
+# Scene kinds.  Every kind is a convex arrangement of planes n.p + d = 0 seen from inside (n.p + d > 0), so the
+# surface a pixel sees is the nearest front-facing plane along its ray.
+#   "dense"      20 random planes n = (u1, u2, -1)/|.| at offset 2.5 m, keyframe poses exp(xi) with xi_t ~ U(-0.25, 0.25) m,
+#                xi_r ~ U(-0.12, 0.12) rad: every keyframe stares at the same planes (the bench headline since round 1).
+#   "survey"     the same planes with the pose ranges of the reference's test scene, xi_t ~ U(-1.5, 1.5) m, xi_r ~ U(-0.7, 0.7) rad
+#                (BS/test/test_intrinsics_optimization_geometric_residual.cc:286-296).
+#   "trajectory" a room (16 jittered walls around a 5 m apothem, floor, ceiling) and a camera that walks one smooth lap at
+#                2.2 m from the centre looking outward, K poses along the lap: a keyframe sees a bounded part of the scene
+#                (about a tenth of the wall ring), as on a real sequence.
+SCENE_KINDS = ("dense", "survey", "trajectory")
+POSE_RANGES = {"dense": (0.25, 0.12), "survey": (1.5, 0.7)}
 
-    def __init__(self, num_keyframes, width=640, height=480, cell=4, seed=0xBAD51A4,
-                 fx=525.0, fy=525.0, cx=320.0, cy=240.0, raw_to_float_depth=1.0 / 5000, baseline_fx=40.0,
-                 translation_range=0.25, rotation_range=0.12, plane_count=20, surfel_noise=0.002):
-        rng = np.random.default_rng(seed)
-        self.width, self.height, self.cell = width, height, cell
-        self.camera = abi.Camera4f(fx, fy, cx, cy, width, height)   # pixel-corner convention
-        self.raw_to_float_depth = np.float32(raw_to_float_depth)
-        self.baseline_fx = float(baseline_fx)
-        self.K = num_keyframes
+
+def rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
+
+
+def rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], np.float64)
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float64)
+
+
+def scene_planes(kind, rng, plane_count=20):
+    """(normals [P, 3], offsets [P]) of the scene's planes n.p + d = 0; the free space is n.p + d > 0 for every plane."""
+    if kind in ("dense", "survey"):
         planes = []
         for _ in range(plane_count):
             n = rng.uniform(-1, 1, 3)
             n[2] = -1.0
             planes.append(n / np.linalg.norm(n))
-        plane_matrix = np.stack(planes, axis=0)
+        return np.stack(planes, axis=0), np.full(plane_count, 2.5)
+    if kind != "trajectory":
+        raise ValueError(f"unknown scene kind {kind!r}")
+    normals, offsets = [], []
+    walls = 16
+    for i in range(walls):
+        th = 2 * np.pi * i / walls
+        n = -np.array([np.cos(th), 0.0, np.sin(th)]) + rng.uniform(-0.08, 0.08, 3)   # inward, slightly tilted
+        normals.append(n / np.linalg.norm(n))
+        offsets.append(5.0 + rng.uniform(-0.4, 0.4))
+    for sign in (+1.0, -1.0):   # floor (y = +1.4: y points down in the camera convention) and ceiling
+        n = np.array([0.0, -sign, 0.0]) + rng.uniform(-0.03, 0.03, 3)
+        normals.append(n / np.linalg.norm(n))
+        offsets.append(1.4 + rng.uniform(-0.05, 0.05))
+    return np.stack(normals, axis=0), np.array(offsets)
+
+
+def trajectory_pose(k, K):
+    """(R, t) = global_T_frame of pose k of K along one smooth lap through the room of scene_planes("trajectory"): the camera
+    (z forward, x right, y down) stands about 2.2 m from the room's axis and looks outward, with slow changes of radius,
+    height, heading, pitch and roll."""
+    phi = 2 * np.pi * k / K
+    radius = 2.2 + 0.3 * np.sin(2 * phi + 1.0)
+    t = np.array([radius * np.cos(phi), 0.25 * np.sin(3 * phi), radius * np.sin(phi)])
+    heading = phi + 0.25 * np.sin(5 * phi)
+    R = rot_y(np.pi / 2 - heading) @ rot_x(0.15 * np.sin(4 * phi + 0.5)) @ rot_z(0.05 * np.sin(7 * phi))
+    return R, t
+
+
+class SyntheticStack:
+    """Host arrays of a synthetic keyframe stack + surfel SoA."""
+
+    def __init__(self, num_keyframes, width=640, height=480, cell=4, seed=0xBAD51A4,
+                 fx=525.0, fy=525.0, cx=320.0, cy=240.0, raw_to_float_depth=1.0 / 5000, baseline_fx=40.0,
+                 translation_range=None, rotation_range=None, plane_count=20, surfel_noise=0.002, kind="dense"):
+        rng = np.random.default_rng(seed)
+        self.kind = kind
+        if kind in POSE_RANGES:
+            translation_range = POSE_RANGES[kind][0] if translation_range is None else translation_range
+            rotation_range = POSE_RANGES[kind][1] if rotation_range is None else rotation_range
+        self.width, self.height, self.cell = width, height, cell
+        self.camera = abi.Camera4f(fx, fy, cx, cy, width, height)   # pixel-corner convention
+        self.raw_to_float_depth = np.float32(raw_to_float_depth)
+        self.baseline_fx = float(baseline_fx)
+        self.K = num_keyframes
+        plane_matrix, plane_d = scene_planes(kind, rng, plane_count)
         xs = (np.arange(width) - (cx - 0.5)) / fx
         ys = (np.arange(height) - (cy - 0.5)) / fy
         dxg, dyg = np.meshgrid(xs, ys)
@@ -125,14 +189,17 @@ class SyntheticStack:
         surf = []
         cw, ch = (width - 1) // cell + 1, (height - 1) // cell + 1
         for k in range(num_keyframes):
-            xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
-            R, t = se3_exp(xi)
+            if kind == "trajectory":
+                R, t = trajectory_pose(k, num_keyframes)
+            else:
+                xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
+                R, t = se3_exp(xi)
             self.R.append(R)
             self.t.append(t)
             dg = dirs @ R.T
             # nearest front-facing plane per pixel, all planes at once (first plane wins ties, as a plane-by-plane sweep would)
             denom = dg @ plane_matrix.T                                  # [h, w, planes]
-            num = -(2.5 + plane_matrix @ t)
+            num = -(plane_d + plane_matrix @ t)
             with np.errstate(divide="ignore", invalid="ignore"):
                 tt = num[None, None, :] / denom
             tt = np.where((denom < 0) & (tt > 0.3), tt, np.inf)
@@ -252,27 +319,31 @@ class TorchStack(DeviceStack):
     copied back from the device."""
 
     def __init__(self, num_keyframes, device, width=640, height=480, cell=4, seed=0xBAD51A4, fx=525.0, fy=525.0, cx=320.0, cy=240.0,
-                 raw_to_float_depth=1.0 / 5000, baseline_fx=40.0, translation_range=0.25, rotation_range=0.12, plane_count=20,
-                 surfel_noise=0.002):
+                 raw_to_float_depth=1.0 / 5000, baseline_fx=40.0, translation_range=None, rotation_range=None, plane_count=20,
+                 surfel_noise=0.002, kind="dense"):
         import torch
         self.torch = torch
         self.device = device
+        self.kind = kind
+        if kind in POSE_RANGES:
+            translation_range = POSE_RANGES[kind][0] if translation_range is None else translation_range
+            rotation_range = POSE_RANGES[kind][1] if rotation_range is None else rotation_range
         rng = np.random.default_rng(seed)
-        planes = []
-        for _ in range(plane_count):
-            n = rng.uniform(-1, 1, 3)
-            n[2] = -1.0
-            planes.append(n / np.linalg.norm(n))
+        planes, plane_d = scene_planes(kind, rng, plane_count)
         Rs, ts = [], []
-        for _ in range(num_keyframes):
-            xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
-            R, t = se3_exp(xi)
+        for k in range(num_keyframes):
+            if kind == "trajectory":
+                R, t = trajectory_pose(k, num_keyframes)
+            else:
+                xi = np.concatenate([rng.uniform(-translation_range, translation_range, 3), rng.uniform(-rotation_range, rotation_range, 3)])
+                R, t = se3_exp(xi)
             Rs.append(R)
             ts.append(t)
         cam = abi.Camera4f(fx, fy, cx, cy, width, height)
         self.stack = GeneratedStackMeta(num_keyframes, width, height, cell, cam, raw_to_float_depth, baseline_fx, Rs, ts)
         f64 = dict(dtype=torch.float64, device=device)
-        P = torch.tensor(np.stack(planes), **f64)                                   # [planes, 3]
+        P = torch.tensor(np.asarray(planes), **f64)                                 # [planes, 3]
+        Pd = torch.tensor(np.asarray(plane_d), **f64)                               # [planes]
         xs = (torch.arange(width, **f64) - (cx - 0.5)) / fx
         ys = (torch.arange(height, **f64) - (cy - 0.5)) / fy
         dyg, dxg = torch.meshgrid(ys, xs, indexing="ij")
@@ -300,7 +371,7 @@ class TorchStack(DeviceStack):
             t = torch.tensor(ts[k], **f64)
             dg = dirs @ R.T
             denom = dg @ P.T
-            num = -(2.5 + P @ t)
+            num = -(Pd + P @ t)
             tt = num[None, None, :] / denom
             tt = torch.where((denom < 0) & (tt > 0.3), tt, torch.full_like(tt, float("inf")))
             best, which = tt.min(dim=2)

@@ -184,7 +184,9 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
  * bslam_profile_read synchronises those events and returns launches and summed ms since
  * the last enable/read. */
 int bslam_profile_enable(bslam_context* ctx, int enable);
-enum { BSLAM_PROF_POSE_ACCUMULATE = 0, BSLAM_PROF_GEOMETRY = 1, BSLAM_PROF_PCG_INIT = 2, BSLAM_PROF_PCG_STEP1 = 3, BSLAM_PROF_ACTIVATION = 4 };
+enum { BSLAM_PROF_POSE_ACCUMULATE = 0, BSLAM_PROF_GEOMETRY = 1, BSLAM_PROF_PCG_INIT = 2, BSLAM_PROF_PCG_STEP1 = 3, BSLAM_PROF_ACTIVATION = 4,
+       BSLAM_PROF_EXCHANGE = 5,      /* the K x 32 all-reduce of a batched Gauss-Newton iteration (surfel-sharded runs) */
+       BSLAM_PROF_POSE_REDUCE = 6 }; /* row sums + 6x6 solve of a batched Gauss-Newton iteration (single-GPU path) */
 int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float* total_ms);
 /* Work counters accumulated since bslam_profile_enable(ctx, 1) by the counting variants of the kernels (8 values, HOST out):
  * [0] (surfel, keyframe) pairs the activation pass actually visited (it stops at a surfel's first associated active keyframe,
@@ -556,6 +558,8 @@ int bslam_set_allreduce(bslam_context* ctx, bslam_allreduce_fn allreduce, void* 
 int bslam_comm_get_unique_id(void* out_id, size_t bytes);
 int bslam_comm_init(bslam_context* ctx, const void* unique_id, int rank, int world_size);
 int bslam_comm_destroy(bslam_context* ctx);
+/* Rank and size as the communicator itself reports them (ncclCommUserRank / ncclCommCount); 0 and 1 without a communicator. */
+int bslam_comm_query(bslam_context* ctx, int* rank, int* world_size);
 
 /* ------------------------------------------------------------------------- */
 /* PCG (matrix-free Gauss-Newton step)                                        */
