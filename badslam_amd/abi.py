@@ -130,11 +130,12 @@ SIGNATURES = {
     "bslam_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "bslam_comm_destroy": (C.c_int, [C.c_void_p]),
     "bslam_comm_query": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
+    "bslam_set_culling": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_debug_cull_stats": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),
     "bslam_profile_read_counters": (C.c_int, [C.c_void_p, P(C.c_uint64)]),
     "bslam_set_geometry_keyframe_chunk": (C.c_int, [C.c_void_p, C.c_int]),
-    "bslam_set_geometry_descriptor_legacy": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_assign_colors": (C.c_int, [C.c_void_p, C.c_void_p, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF]),
     "bslam_debug_decode_normals": (C.c_int, [C.c_void_p, C.c_void_p, P(C.c_float)]),
     "bslam_debug_jacobians": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),

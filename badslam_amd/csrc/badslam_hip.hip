@@ -233,6 +233,7 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
   out->slots = (G + (uint32_t)R - 1) / (uint32_t)R;
   out->slots_per_xcd = (out->slots + 7) / 8;
   out->order = nullptr;
+  out->bounds = nullptr;
   if (perm_out) *perm_out = nullptr;
   if (!ctx->use_schedule || G < 64) return BSLAM_OK;   // tiny problems: identity order
   const bool want_perm = perm_out != nullptr && keyframe_count >= kPermMinKeyframes;
@@ -338,15 +339,22 @@ static int prepare_surfels(bslam_context* ctx, hipStream_t stream, const bslam_b
   const size_t pitch = ((size_t)surfels_size + 63) & ~(size_t)63;
   if ((rc = ctx->sorted_rows.reserve(7 * pitch * sizeof(float)))) return rc;
   float* out = (float*)ctx->sorted_rows.ptr;
+  // bounding boxes of the granules of the copy, from the very values the kernels will read (frustum culling)
+  float4* bounds = nullptr;
+  if (ctx->culling) {
+    if ((rc = ctx->bounds.reserve(2 * (size_t)w->sc.granules * sizeof(float4)))) return rc;
+    bounds = (float4*)ctx->bounds.ptr;
+  }
   // the copy costs a scattered 4-byte read per row and surfel: rows the call's kernels never read (radius, descriptors in a
   // geometry-only call) are left out
   if (need_descriptor_rows)
-    hipLaunchKernelGGL(permute_surfel_rows_kernel<7>, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
-                       surfels->pitch / sizeof(float), out, pitch);
+    hipLaunchKernelGGL(permute_surfel_rows_kernel<7>, dim3(w->sc.granules), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
+                       surfels->pitch / sizeof(float), out, pitch, bounds);
   else
-    hipLaunchKernelGGL(permute_surfel_rows_kernel<4>, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
-                       surfels->pitch / sizeof(float), out, pitch);
+    hipLaunchKernelGGL(permute_surfel_rows_kernel<4>, dim3(w->sc.granules), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
+                       surfels->pitch / sizeof(float), out, pitch, bounds);
   BSLAM_HIP_TRY(hipGetLastError());
+  w->sc.bounds = bounds;
   w->rows.x = out; w->rows.y = out + pitch; w->rows.z = out + 2 * pitch;
   w->rows.normal = (const uint32_t*)(out + 3 * pitch);
   w->rows.radius_squared = out + 4 * pitch;
@@ -385,11 +393,16 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
   return per_block;
 }
 
+// Device counters of the cull statistics (bslam_debug_cull_stats), maintained while profiling is on.
+static unsigned long long* cull_stats_ptr(bslam_context* ctx) {
+  return ctx->profiling ? (unsigned long long*)((uint8_t*)ctx->misc.ptr + kMiscCullStats) : nullptr;
+}
+
 // `work`: the prepared schedule + rows of this API call (prepare_surfels; the batched Gauss-Newton loop prepares them once for
 // all its iterations), or nullptr to prepare them here.
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
-                                  int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr) {
+                                  int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr, int* kfs_per_block_out = nullptr) {
   SurfelWork local;
   int rc = BSLAM_OK;
   if (!work) {
@@ -405,8 +418,11 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   if (rc) return rc;
   rc = ctx->coeffs.reserve((size_t)kf_count * kRow * sizeof(float));
   if (rc) return rc;
-  const int per_block = choose_kfs_per_block(tiles, kf_count);
+  const int per_block = choose_kfs_per_block(tiles, kf_count);   // <= 32: one bit per keyframe of a chunk in a vis word
   const unsigned chunks = (unsigned)((kf_count + per_block - 1) / per_block);
+  if (kfs_per_block_out) *kfs_per_block_out = per_block;
+  if ((rc = ctx->vis.reserve((size_t)chunks * sc.slots * sizeof(uint32_t)))) return rc;
+  uint32_t* vis = (uint32_t*)ctx->vis.ptr;
   dim3 grid(8u * sc.slots_per_xcd * chunks);
   const SurfelRows rows = work->rows;
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
@@ -415,17 +431,17 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   static const unsigned debug_lds = getenv("BSLAM_DEBUG_POSE_LDS") ? (unsigned)atoi(getenv("BSLAM_DEBUG_POSE_LDS")) : 0u;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeoLarge>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
+  else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeoLarge>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
   }
   BSLAM_HIP_TRY(hipGetLastError());
   if (!reduce_rows) return BSLAM_OK;   // the caller's pose_reduce_solve_kernel sums the rows itself
   // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a thread's
   // share at most rows / 32 * 256 -- exact in fp32 up to 2^24
-  hipLaunchKernelGGL(pose_reduce_rows_kernel, dim3((unsigned)kf_count), dim3(1024), 0, stream, (const float*)partials, rows_per_kf, kf_count,
-                     (float*)ctx->coeffs.ptr, states);
+  hipLaunchKernelGGL(pose_reduce_rows_kernel, dim3((unsigned)kf_count), dim3(1024), (unsigned)visit_map_bytes(tiles), stream, (const float*)partials, rows_per_kf, kf_count,
+                     (float*)ctx->coeffs.ptr, states, (const uint32_t*)vis, per_block, cull_stats_ptr(ctx));
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -516,6 +532,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   int rc = ctx->misc.reserve(256);
   if (rc) { delete ctx; return rc; }
+  if (hipMemset(ctx->misc.ptr, 0, 256) != hipSuccess) { delete ctx; return fail(BSLAM_ERR_HIP, "hipMemset failed"); }
   *out_ctx = ctx;
   return BSLAM_OK;
 }
@@ -524,7 +541,7 @@ int bslam_destroy(bslam_context* ctx) {
   if (!ctx) return BSLAM_OK;
   hipError_t e = hipSetDevice(ctx->device); (void)e;
   bslam_comm_destroy(ctx);
-  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->centroids.release(); ctx->perm.release(); ctx->sorted_rows.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
+  ctx->kf_table.release(); ctx->partials.release(); ctx->coeffs.release(); ctx->pose_state.release(); ctx->misc.release(); ctx->records.release(); ctx->quads.release(); ctx->exchange.release(); ctx->lifecycle.release(); ctx->quads_aux.release(); ctx->order.release(); ctx->centroids.release(); ctx->perm.release(); ctx->sorted_rows.release(); ctx->bounds.release(); ctx->vis.release(); ctx->intr_cells.release(); ctx->prof_counters.release();
   ctx->staging.release(); ctx->staging2.release(); ctx->upload_ring.release();
   for (hipEvent_t& e : ctx->iter_done) if (e) { hipError_t err = hipEventDestroy(e); (void)err; e = nullptr; }
   if (ctx->perm_ready) { hipError_t err = hipEventDestroy(ctx->perm_ready); (void)err; ctx->perm_ready = nullptr; }
@@ -625,6 +642,24 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable) {
   return BSLAM_OK;
 }
 
+int bslam_set_culling(bslam_context* ctx, int enable) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  ctx->culling = enable != 0;
+  return BSLAM_OK;
+}
+
+int bslam_debug_cull_stats(bslam_context* ctx, uint64_t* tested, uint64_t* culled) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  BSLAM_HIP_TRY(hipDeviceSynchronize());
+  unsigned long long h[2] = {0, 0};
+  BSLAM_HIP_TRY(hipMemcpy(h, (uint8_t*)ctx->misc.ptr + kMiscCullStats, sizeof(h), hipMemcpyDeviceToHost));
+  BSLAM_HIP_TRY(hipMemset((uint8_t*)ctx->misc.ptr + kMiscCullStats, 0, sizeof(h)));
+  if (tested) *tested = h[0];
+  if (culled) *culled = h[0] - h[1];
+  return BSLAM_OK;
+}
+
 int bslam_profile_enable(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->profiling = enable != 0;
@@ -674,12 +709,6 @@ int bslam_profile_read(bslam_context* ctx, int kernel, int32_t* launches, float*
 int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch) {
   if (!ctx || keyframes_per_launch < -1) return fail(BSLAM_ERR_INVALID_ARGUMENT, "bad argument");
   ctx->geom_kf_chunk = keyframes_per_launch;
-  return BSLAM_OK;
-}
-
-int bslam_set_geometry_descriptor_legacy(bslam_context* ctx, int enable) {
-  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
-  ctx->geom_desc_legacy = enable != 0;
   return BSLAM_OK;
 }
 
@@ -900,13 +929,14 @@ int bslam_estimate_frame_poses_batched(
     // Later slots are zeroed by the previous iteration's solve kernel.
     if (it == 0) BSLAM_HIP_TRY(hipMemsetAsync(d_active + slot, 0, sizeof(int), stream));
     if (fused) {
-      int tiles = 0;
-      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work);
+      int tiles = 0, per_block = 1;
+      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work, &per_block);
       if (r) return r;
       {
         ProfScope prof(ctx, stream, BSLAM_PROF_POSE_REDUCE);
-        hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), 0, stream, (const float*)ctx->partials.ptr,
-                           tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3));
+        hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), (unsigned)visit_map_bytes(tiles), stream, (const float*)ctx->partials.ptr,
+                           tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3),
+                           (const uint32_t*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx));
       }
       BSLAM_HIP_TRY(hipGetLastError());
     } else {
@@ -1026,8 +1056,9 @@ int bslam_update_surfel_normals(
   SurfelWork work;
   if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, 1, keyframe_count, &work, false))) return rc;
   const Schedule sc = work.sc;
-  hipLaunchKernelGGL((geometry_kernel<0, true>), dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, keyframe_count, sc,
-                     surfel_rows_rw(work, surfels, active_surfels, surfels_size));
+  // the normals pass of the geometry iteration on its own: one launch over the whole keyframe list (first and last chunk)
+  hipLaunchKernelGGL((geometry_chunk_kernel<1, 0>), dim3(8u * sc.slots_per_xcd), dim3(256), 0, stream, c, (const KfDev*)ctx->kf_table.ptr, 0, keyframe_count, 1, 1, sc, 0u,
+                     surfel_rows_rw(work, surfels, active_surfels, surfels_size), (float*)nullptr, 0u);
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -1059,7 +1090,7 @@ int bslam_optimize_geometry_iteration(
 #define BSLAM_GEOM_R_DESC 2
 #endif
   SurfelWork work;
-  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? (ctx->geom_desc_legacy ? 1 : BSLAM_GEOM_R_DESC) : BSLAM_GEOM_R, keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
+  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, use_descriptor_residuals ? BSLAM_GEOM_R_DESC : BSLAM_GEOM_R, keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
   const Schedule sc = work.sc;
   const dim3 grid(8u * sc.slots_per_xcd), block(256);
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
@@ -1087,10 +1118,7 @@ int bslam_optimize_geometry_iteration(
       }
     }
   }
-  else if (ctx->geom_desc_legacy) {   // one surfel per thread, one launch over the whole keyframe list (A/B measurements)
-    if (use_depth_residuals) hipLaunchKernelGGL((geometry_kernel<2, true>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
-    else hipLaunchKernelGGL((geometry_kernel<2, false>), grid, block, 0, stream, c, kfs, keyframe_count, sc, rows);
-  } else {
+  else {
     // photometric iteration: BSLAM_GEOM_R_DESC surfels per thread, one launch per pass over all surfels and keyframes (K = 300:
     // 22.0 ms per iteration with resident-grid launches, 16.5 ms with one); optional keyframe chunks with the per-surfel sums
     // carried in scratch (4 floats for the normals pass, 8 for the joint position + descriptor pass)

@@ -33,6 +33,10 @@ inline int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return ::bslam::fail(BSLAM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// Byte offsets of the small device scalars in bslam_context::misc (256 bytes, zeroed at creation): [0, 16) active-keyframe
+// counters of the batched pose loop, [64, 80) pair census, [128, 192) PCG scalars, [192, 224) lifecycle / preprocessing counters.
+constexpr size_t kMiscCullStats = 224;   // unsigned long long[2]: (work slot, keyframe) pairs tested / visited by the pose kernel
+
 // A device slab that only ever grows.
 struct Slab {
   void* ptr = nullptr;
@@ -121,7 +125,6 @@ struct bslam_context {
   bslam::Slab misc;          // small device scalars
   bslam::Slab intr_cells;    // B[5][cells], D, b2, obs of the intrinsics step; or the PCG path's fp64 cell sums
   int geom_kf_chunk = -1;    // geometry iteration: keyframes per launch (0: one launch for the whole list; -1: default = one launch)
-  bool geom_desc_legacy = false;   // photometric geometry iteration as one launch of geometry_kernel<2> (A/B measurements, parity tests)
   int intr_cells_owner = 0;  // 0: intrinsics step (zeroes per call), 1: PCG (kept zero between calls)
   size_t intr_cells_cells = 0;
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
@@ -144,6 +147,9 @@ struct bslam_context {
   bslam::Slab centroids;     // granule centroids (scratch of make_schedule)
   bslam::Slab perm;          // per-surfel Morton order (+ sort scratch), cached like `order`
   bslam::Slab sorted_rows;   // the seven persistent surfel rows in that order, rebuilt by every call that uses it
+  bslam::Slab bounds;        // float4[2 * granules]: bounding box of every granule of the sorted copy, rebuilt with it
+  bslam::Slab vis;           // uint32[chunks][slots]: keyframes of a chunk a work slot visited in the last pose_accumulate launch
+  bool culling = true;       // block-level frustum culling in the pair kernels (bslam_set_culling)
   const void* perm_key_ptr = nullptr;
   uint32_t perm_key_size = 0;
   size_t perm_key_pitch = 0;

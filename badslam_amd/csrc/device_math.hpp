@@ -714,6 +714,7 @@ struct Schedule {
   uint32_t granules;       // ceil(S / 256)
   uint32_t slots;          // ceil(granules / R): work items of R granules each
   uint32_t slots_per_xcd;  // ceil(slots / 8)
+  const float4* bounds;    // per-granule bounding boxes of the sorted copy (block-level frustum culling), or nullptr: no culling
 };
 
 // Work slot of block index b (of a 1-D launch of 8 * slots_per_xcd blocks), or false.
@@ -732,6 +733,92 @@ __device__ __forceinline__ uint32_t surfel_of_slot(const Schedule& sc, uint32_t 
   const uint32_t g = sc.order ? sc.order[pos] : pos;
   return g * kGranule + threadIdx.x;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Block-level frustum culling.  With the per-surfel Morton order the surfels of a work slot (R granules of 256 consecutive
+// positions of the sorted copy) are a compact blob; prepare_surfels stores the axis-aligned bounding box of every granule of
+// that copy.  Before it walks its keyframes, a wave decides for 64 keyframes at once -- one keyframe per lane -- whether ANY
+// point of the slot's box can pass project_to_pixel (z > 0 and the four image bounds); keyframes for which none can are not
+// visited at all.  The reference spends a thread on every (surfel, keyframe) pair (BS/kernel_opt_pose.cu:263-275).
+//
+// The test must be exactly conservative: a skipped (slot, keyframe) may contain no pair that passes project_to_pixel as the
+// kernels evaluate it in fp32.  Every inequality below is therefore relaxed by kCullSlack times the sum of the MAGNITUDES of
+// the terms it is made of (not of their possibly cancelling sum): the kernels' own rounding of local = T * p and of the
+// projection is bounded by a few 2^-24 of the same magnitudes, i.e. by < 1e-6 of them, and so is the rounding of the test
+// itself; 1e-4 leaves two orders of magnitude and costs a band of < 1 px around the image.  NaN or infinite boxes (deleted
+// surfels carry x = NaN) make every comparison false: not culled.
+// ---------------------------------------------------------------------------------------------
+constexpr float kCullSlack = 1e-4f;
+struct SlotBox { f3 c, e; };   // centre and half extents in global coordinates
+
+// Box of work slot `slot` (R granules) from the per-granule boxes {min.xyz, -}, {max.xyz, -}.
+__device__ __forceinline__ SlotBox slot_box(const float4* __restrict__ bounds, uint32_t granules, uint32_t slot, int R) {
+  const float inf = __uint_as_float(0x7f800000u);
+  f3 lo = mk3(inf, inf, inf), hi = mk3(-inf, -inf, -inf);
+  for (int r = 0; r < R; ++r) {
+    const uint32_t pos = slot * (uint32_t)R + (uint32_t)r;
+    if (pos >= granules) break;
+    const float4 a = bounds[2 * (size_t)pos], b = bounds[2 * (size_t)pos + 1];
+    lo = mk3(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
+    hi = mk3(fmaxf(hi.x, b.x), fmaxf(hi.y, b.y), fmaxf(hi.z, b.z));
+  }
+  SlotBox o;
+  o.c = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+  o.e = mk3(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z));
+  return o;
+}
+
+// True when no point of the box can pass project_to_pixel under frame_T_global = T (12 floats, row-major 3x4).
+__device__ __forceinline__ bool box_outside_frustum(const CamConsts& c, const float* T, const SlotBox& b) {
+  float cc[3], ee[3], mm[3];   // camera-space centre, half extents of the enclosing camera-aligned box, magnitude of the terms
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a0 = T[4 * i], a1 = T[4 * i + 1], a2 = T[4 * i + 2], a3 = T[4 * i + 3];
+    cc[i] = a0 * b.c.x + a1 * b.c.y + a2 * b.c.z + a3;
+    ee[i] = fabsf(a0) * b.e.x + fabsf(a1) * b.e.y + fabsf(a2) * b.e.z;
+    mm[i] = fabsf(a0) * fabsf(b.c.x) + fabsf(a1) * fabsf(b.c.y) + fabsf(a2) * fabsf(b.c.z) + fabsf(a3) + ee[i];
+  }
+  const float w = (float)c.width, h = (float)c.height;
+  // local.z <= 0 for every point
+  bool out = cc[2] + ee[2] < -kCullSlack * mm[2];
+  // pxy.x < 0 for every point with z > 0:   fx x + cx z < 0
+  out |= (c.fx * cc[0] + c.cx * cc[2]) + (c.fx * ee[0] + fabsf(c.cx) * ee[2]) < -kCullSlack * (c.fx * mm[0] + fabsf(c.cx) * mm[2]);
+  // pxy.x >= width for every point with z > 0:   fx x + (cx - w) z >= 0
+  out |= (c.fx * cc[0] + (c.cx - w) * cc[2]) - (c.fx * ee[0] + fabsf(c.cx - w) * ee[2]) > kCullSlack * (c.fx * mm[0] + fabsf(c.cx - w) * mm[2]);
+  // the same for y
+  out |= (c.fy * cc[1] + c.cy * cc[2]) + (c.fy * ee[1] + fabsf(c.cy) * ee[2]) < -kCullSlack * (c.fy * mm[1] + fabsf(c.cy) * mm[2]);
+  out |= (c.fy * cc[1] + (c.cy - h) * cc[2]) - (c.fy * ee[1] + fabsf(c.cy - h) * ee[2]) > kCullSlack * (c.fy * mm[1] + fabsf(c.cy - h) * mm[2]);
+  return out;
+}
+
+// Keyframes k0 + lane, lane = 0 .. 63, below k_end: bit `lane` of the result is set when the keyframe has to be visited
+// (`wanted` is the caller's own per-lane condition -- not converged, not inactive -- and `bounds` == nullptr means no
+// culling).  Uniform across the wave.
+__device__ __forceinline__ unsigned long long keyframes_to_visit(const CamConsts& c, const KfDev* __restrict__ kfs, int k0, int k_end, bool culling,
+                                                                 const SlotBox& box, bool wanted) {
+  const int k = k0 + (int)(threadIdx.x & 63u);
+  bool visit = k < k_end && wanted;
+  if (visit && culling) {
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = kfs[k].frame_T_global.m[i];
+    visit = !box_outside_frustum(c, T, box);
+  }
+  return __ballot(visit);
+}
+
+// Walks the keyframes of [k_begin, k_end) that are not INACTIVE and that the slot's box reaches, in list order (64 keyframes
+// are decided at a time, one per lane): inside the body, `K_` is the keyframe's index.  Needs c, kfs, sc and box in scope.
+__device__ __forceinline__ bool keyframe_not_inactive(const KfDev* __restrict__ kfs, int k0, int k_end) {
+  const int k = k0 + (int)(threadIdx.x & 63u);
+  return k < k_end && kfs[k].activation != BSLAM_KF_INACTIVE;
+}
+#define BSLAM_FOR_VISITED_KEYFRAMES(K_, k_begin, k_end)                                                                        \
+  for (int k0_ = (k_begin); k0_ < (k_end); k0_ += 64)                                                                          \
+    for (unsigned long long todo_ = keyframes_to_visit(c, kfs, k0_, (k_end), sc.bounds != nullptr, box,                        \
+                                                       keyframe_not_inactive(kfs, k0_, (k_end)));                              \
+         todo_ != 0; todo_ &= todo_ - 1)                                                                                       \
+      if (const int K_ = k0_ + __builtin_ctzll(todo_); true)
 
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions

@@ -41,16 +41,49 @@ __device__ __forceinline__ void store_descriptor1(const SurfelRowsRW& s, uint32_
 __device__ __forceinline__ void store_descriptor2(const SurfelRowsRW& s, uint32_t j, float v) { s.d2[j] = v; if (s.perm) s.od2[s.perm[j]] = v; }
 
 // Sorted copy of the seven persistent surfel rows the pair kernels read: out row r, position j = in row r, column perm[j].
-// kRows = 4: position + normal only (what the geometry-only kernels read).
+// kRows = 4: position + normal only (what the geometry-only kernels read).  A block is one granule of the copy: it also
+// stores the granule's axis-aligned bounding box (bounds[2 g] = min, bounds[2 g + 1] = max; NaN coordinates -- deleted
+// surfels -- are ignored by fminf / fmaxf), the input of the block-level frustum culling (device_math.hpp).
 template <int kRows>
 __global__ __launch_bounds__(256) void permute_surfel_rows_kernel(const uint32_t* __restrict__ perm, uint32_t size, const float* __restrict__ in, size_t in_pitch_floats,
-                                                                 float* __restrict__ out, size_t out_pitch_floats) {
+                                                                 float* __restrict__ out, size_t out_pitch_floats, float4* __restrict__ bounds) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= size) return;
-  const uint32_t i = perm[j];
-  const int rows[7] = {BSLAM_SURFEL_X, BSLAM_SURFEL_Y, BSLAM_SURFEL_Z, BSLAM_SURFEL_NORMAL, BSLAM_SURFEL_RADIUS_SQUARED, BSLAM_SURFEL_DESCRIPTOR1, BSLAM_SURFEL_DESCRIPTOR2};
+  const float inf = __uint_as_float(0x7f800000u);
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  if (j < size) {
+    const uint32_t i = perm[j];
+    const int rows[7] = {BSLAM_SURFEL_X, BSLAM_SURFEL_Y, BSLAM_SURFEL_Z, BSLAM_SURFEL_NORMAL, BSLAM_SURFEL_RADIUS_SQUARED, BSLAM_SURFEL_DESCRIPTOR1, BSLAM_SURFEL_DESCRIPTOR2};
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) out[(size_t)r * out_pitch_floats + j] = in[(size_t)rows[r] * in_pitch_floats + i];
+    for (int r = 0; r < kRows; ++r) {
+      const float v = in[(size_t)rows[r] * in_pitch_floats + i];
+      out[(size_t)r * out_pitch_floats + j] = v;
+      if (r < 3) { lo[r] = v; hi[r] = v; }
+    }
+  }
+  if (bounds == nullptr) return;
+  __shared__ float sm[4][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(fminf(sm[0][a], sm[1][a]), fminf(sm[2][a], sm[3][a]));
+      hi[a] = fmaxf(fmaxf(sm[0][3 + a], sm[1][3 + a]), fmaxf(sm[2][3 + a], sm[3][3 + a]));
+    }
+    bounds[2 * (size_t)blockIdx.x] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    bounds[2 * (size_t)blockIdx.x + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
 }
 
 // SetSurfelInactiveKernel + K x DetermineActiveSurfelsKernel (BS/kernel_surfel_activation.cu:38-79)
@@ -313,140 +346,10 @@ __global__ __launch_bounds__(256) void residual_probe_kernel(CamConsts c, const 
   for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = o[k];
 }
 
-// Geometry step of one BA iteration for one surfel.
-//   kMode 0: normals only                  (UpdateSurfelNormalsCUDA, BS/kernel_opt_geometry.cc:39-78)
-//   kMode 1: normals, then position        (geometry-only,  BS/kernel_opt_geometry.cc:137-169)
-//   kMode 2: normals, then position + descriptors jointly   (BS/kernel_opt_geometry.cc:170-200)
-template <int kMode, bool kDepth>
-__global__ __launch_bounds__(256) void geometry_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRowsRW s) {
-  uint32_t slot;
-  if (!slot_of_block(sc, blockIdx.x, &slot)) return;
-  const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
-  if (i >= s.size) return;
-  if (!(s.active[column_of(s, i)] & BSLAM_SURFEL_ACTIVE_FLAG)) return;
-  f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
-  uint32_t packed = s.normal[i];
-  f3 gn = unpack_normal(packed);
-
-  // ---- normals: mean of the associated pixel normals, rotated to global
-  // (BS/kernel_opt_geometry.cu:527-557, 577-597)
-  {
-    float sx = 0, sy = 0, sz = 0, cnt = 0;
-    for (int k = 0; k < kf_count; ++k) {
-      const KfDev kf = kfs[k];
-      if (kf.activation == BSLAM_KF_INACTIVE) continue;
-      Proj p;
-      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
-      const f3 ln = p.pixel_normal;
-      const float* R = kf.global_R_frame;
-      sx += rot_row(R[0], R[1], R[2], ln);
-      sy += rot_row(R[3], R[4], R[5], ln);
-      sz += rot_row(R[6], R[7], R[8], ln);
-      cnt += 1.f;
-    }
-    if (cnt >= 1) {
-      const float inv = 1.f / cnt;
-      packed = pack_normal(mk3(inv * sx, inv * sy, inv * sz));
-      store_normal(s, i, packed);
-      gn = unpack_normal(packed);
-    }
-  }
-  if (kMode == 0) return;
-
-  if (kMode == 1) {
-    // ---- position along the normal from depth residuals (BS/kernel_opt_geometry.cu:417-459, 487-507)
-    float H = 0, b = 0;
-    for (int k = 0; k < kf_count; ++k) {
-      const KfDev kf = kfs[k];
-      if (kf.activation == BSLAM_KF_INACTIVE) continue;
-      Proj p;
-      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
-      const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, p.n_local, c.baseline_fx);
-      const float dj = depth_position_jacobian(inv_stddev);
-      const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-      const float raw = depth_residual(inv_stddev, p.n_local, lu, p.local);
-      const float w = depth_weight(raw);
-      const float wj = w * dj;
-      H += wj * dj;
-      b += wj * raw;
-    }
-    if (H > 1e-6f) {
-      const float t = -1.f * b / H;
-      gp = add3(gp, scale3(t, gn));
-      store_position(s, i, gp);
-    }
-    return;
-  }
-
-  if (kMode == 2) {
-    // ---- joint position + descriptor step (BS/kernel_opt_geometry.cu:118-231, 273-361)
-    float A0 = 0, A1 = 0, A2 = 0, A3 = 0, A5 = 0, A6 = 0, A7 = 0, A8 = 0;   // A4 = H(1,2) is never accumulated (quirk Q2)
-    const float desc1 = s.d1[i], desc2 = s.d2[i];
-    f3 tp1, tp2;
-    tangent_points(gp, gn, s.radius_squared[i], &tp1, &tp2);
-    for (int k = 0; k < kf_count; ++k) {
-      const KfDev kf = kfs[k];
-      if (kf.activation == BSLAM_KF_INACTIVE) continue;
-      Proj p;
-      if (!project_and_associate(c, kf, gp, gn, &p)) continue;
-      const f3 rn = p.n_local;
-      if (kDepth) {
-        const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
-        const float dj = depth_position_jacobian(inv_stddev);
-        const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
-        const float raw = depth_residual(inv_stddev, rn, lu, p.local);
-        const float w = depth_weight(raw);
-        A0 += w * dj * dj;
-        A6 += w * raw * dj;
-      }
-      f2 color_pxy;
-      if (depth_to_color_pxy(c, p.pxy, &color_pxy)) {
-        f2 t1, t2;
-        project_tangent_points(tp1, tp2, kf.frame_T_global, c, &t1, &t2);
-        float r1, rr2, gx1, gy1, gx2, gy2;
-        descriptor_residual_and_jacobian(kf, c, color_pxy, t1, t2, desc1, desc2, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-        const float jp1 = descriptor_position_jacobian(gx1, gy1, c.cfx, c.cfy, rn, p.local);
-        const float jp2 = descriptor_position_jacobian(gx2, gy2, c.cfx, c.cfy, rn, p.local);
-        const float jd = -1.f;
-        const float w1 = desc_weight(r1);
-        const float wr1 = w1 * r1;
-        const float w2 = desc_weight(rr2);
-        const float wr2 = w2 * rr2;
-        A0 += w1 * jp1 * jp1 + w2 * jp2 * jp2;
-        A1 += w1 * jp1 * jd;
-        A3 += w1 * jd * jd;
-        A6 += wr1 * jp1 + wr2 * jp2;
-        A7 += wr1 * jd;
-        A2 += w2 * jp2 * jd;
-        A5 += w2 * jd * jd;
-        A8 += wr2 * jd;
-      }
-    }
-    float H00 = A0, H01 = A1, H02 = A2, H11 = A3, H12 = 0.f, H22 = A5;
-    H00 += 1e-6f; H11 += 1e-6f; H22 += 1e-6f;
-    H00 = sqrtf(H00);
-    H01 = H01 / H00;
-    H11 = sqrtf(H11 - H01 * H01);
-    H02 = H02 / H00;
-    H12 = (H12 - H02 * H01) / H11;
-    H22 = sqrtf(H22 - H02 * H02 - H12 * H12);
-    const float y0 = A6 / H00;
-    const float y1 = (A7 - H01 * y0) / H11;
-    const float y2 = (A8 - H02 * y0 - H12 * y1) / H22;
-    const float x2 = y2 / H22;
-    const float x1 = (y1 - H12 * x2) / H11;
-    const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
-    if (x0 != 0) {
-      gp = sub3(gp, scale3(x0, gn));
-      store_position(s, i, gp);
-    }
-    if (x1 != 0) store_descriptor1(s, i, fmaxf(-180.f, fminf(180.f, desc1 - x1)));
-    if (x2 != 0) store_descriptor2(s, i, fmaxf(-180.f, fminf(180.f, desc2 - x2)));
-  }
-}
-
-// kMode 1 with R surfels per thread, interleaved keyframe by keyframe: R independent gather chains per thread, per-surfel sums
-// formed in keyframe order (same bits as the R = 1 kernel).  One launch covers all surfels (first_i = 0); round 1 launched it
+// Geometry-only iteration (normals, then position along the normal: UpdateSurfelNormalsCUDA + OptimizeGeometryIterationCUDA,
+// BS/kernel_opt_geometry.cc:39-78, 137-169; kernels BS/kernel_opt_geometry.cu:417-459, 487-507, 527-597) with R surfels per thread,
+// interleaved keyframe by keyframe: R independent gather chains per thread, per-surfel sums formed in keyframe order -- the order in
+// which the reference's serialised per-keyframe launches add their terms.  One launch covers all surfels (first_i = 0); round 1 launched it
 // one resident grid at a time to keep the workgroups in lockstep on the keyframe table, which the per-surfel work order made
 // unnecessary (first_i = first slot of every XCD's range handled by a launch is kept for that use).
 template <int R>
@@ -466,13 +369,14 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
   }
+  SlotBox box;
+  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
   {
     float sx[R], sy[R], sz[R], cnt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
-    for (int k = 0; k < kf_count; ++k) {
+    BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count) {
       const KfDev kf = kfs[k];
-      if (kf.activation == BSLAM_KF_INACTIVE) continue;
       const float* Rm = kf.global_R_frame;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -498,9 +402,8 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
   float H[R], b[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
-  for (int k = 0; k < kf_count; ++k) {
+  BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count) {
     const KfDev kf = kfs[k];
-    if (kf.activation == BSLAM_KF_INACTIVE) continue;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
@@ -552,9 +455,10 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
       if (kPass == 0) { a2[r] = acc[(size_t)2 * acc_pitch + j]; a3[r] = acc[(size_t)3 * acc_pitch + j]; }
     }
   }
-  for (int k = k_begin; k < k_end; ++k) {
+  SlotBox box;
+  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
+  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end) {
     const KfDev kf = kfs[k];
-    if (kf.activation == BSLAM_KF_INACTIVE) continue;
     const float* Rm = kf.global_R_frame;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -633,9 +537,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
 #pragma unroll
     for (int q = 0; q < kAcc; ++q) a[r][q] = (!first_chunk && on[r]) ? acc[(size_t)q * acc_pitch + j] : 0.f;
   }
-  for (int k = k_begin; k < k_end; ++k) {
+  SlotBox box;
+  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
+  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end) {
     const KfDev kf = kfs[k];
-    if (kf.activation == BSLAM_KF_INACTIVE) continue;
     const float* Rm = kf.global_R_frame;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 template <bool kDepth, bool kDesc, int kPoseR>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
-    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states) {
+    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, uint32_t* __restrict__ vis) {
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
   // blocks run chunk-major over that XCD's range of surfel slots.
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -108,12 +108,20 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   const int kf_end = min(kf_count, kf_begin + kfs_per_block);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  if (states != nullptr) {
-    // late Gauss-Newton iterations: most keyframe chunks have nothing left to do; leave before touching the surfels
-    bool any = false;   // uniform
-    for (int k = kf_begin; k < kf_end; ++k) any = any || !states[k].converged;
-    if (!any) return;
+  // Which keyframes of the chunk (<= 32) this block visits, decided for all of them at once, one keyframe per lane: not
+  // converged (late Gauss-Newton iterations: most chunks have nothing left to do) and -- block-level frustum culling -- the
+  // bounding box of the slot's surfels reaches into the keyframe's image.  The word goes to vis[chunk][slot]: the row sums
+  // (pose_reduce_*_kernel) only read the partial rows of visited (slot, keyframe) pairs, the others are never written.
+  unsigned long long todo;
+  {
+    const int k = kf_begin + lane;
+    const bool wanted = states == nullptr || (k < kf_end && !states[k].converged);
+    SlotBox box;
+    if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, kPoseR);
+    todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc.bounds != nullptr, box, wanted);
   }
+  if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = (uint32_t)todo;
+  if (todo == 0) return;   // leaves before touching the surfels
 
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
@@ -142,8 +150,9 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     }
   }
 
-  for (int k = kf_begin; k < kf_end; ++k) {
-    if (states != nullptr && states[k].converged) continue;   // uniform
+  while (todo != 0) {   // uniform
+    const int k = kf_begin + __builtin_ctzll(todo);
+    todo &= todo - 1;
     const KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
     float acc[kRow];
 #pragma unroll
@@ -257,35 +266,72 @@ __global__ __launch_bounds__(64) void pose_reduce_final_kernel(const float* __re
   }
 }
 
-// Thread (sub, col) of a 1024-thread block adds column `col` of the rows sub, sub + 32, sub + 64, ... of one keyframe.
-// Eight independent partial sums keep eight loads in flight (the walk waits on memory, not on the adds); fixed order.
-__device__ __forceinline__ float column_share_of_rows(const float* __restrict__ base, int sub, int rows) {
-  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int r = sub;
-  for (; r + 7 * 32 < rows; r += 8 * 32) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] += base[(size_t)(r + 32 * u) * kRow];
+// Row sums of one keyframe by a 1024-thread block.  Only the rows of work slots that visited the keyframe exist (vis: one word
+// per slot, bit = the keyframe's place in its chunk; a slot owns kPoseThreads / 64 consecutive rows).  The block first turns
+// the keyframe's bit of every slot's word into a bitmap in LDS (one bit per slot); whole groups of 64 slots (256 rows) that
+// did not visit are then skipped with one uniform test -- in Morton order the visiting slots of a keyframe form a few runs.
+// Thread (sub, col) adds column `col` of the rows sub, sub + 32, sub + 64, ...: row r always goes to thread r % 32 and to its
+// partial sum (r / 32) % 8, whatever was visited, and a row that was not visited would be a row of zeros -- so the sums are the
+// same bits with and without culling.  Eight independent partial sums keep eight loads in flight; a row that is skipped
+// loads a zero from a fixed address instead of branching around the load.
+__device__ const float kZeroFloat = 0.f;
+constexpr int kRowsPerSlot = kPoseThreads / 64;
+__host__ __device__ __forceinline__ size_t visit_map_bytes(int slots) { return (size_t)((slots + 63) / 64) * sizeof(unsigned long long); }
+// Returns the number of visiting slots (valid in every thread after the trailing barrier).
+__device__ __forceinline__ uint32_t build_visit_map(const uint32_t* __restrict__ vis, uint32_t bit, int slots, unsigned long long* __restrict__ vmap) {
+  __shared__ uint32_t visiting;
+  if (threadIdx.x == 0) visiting = 0;
+  __syncthreads();
+  const int padded = (slots + 63) & ~63;
+  uint32_t mine = 0;
+  for (int s0 = 0; s0 < padded; s0 += (int)blockDim.x) {
+    const int sl = s0 + (int)threadIdx.x;
+    const bool v = sl < slots && ((vis[sl] >> bit) & 1u);
+    const unsigned long long w = __ballot(v);
+    if ((threadIdx.x & 63u) == 0 && sl < padded) { vmap[sl >> 6] = w; mine += (uint32_t)__builtin_popcountll(w); }
   }
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&visiting, mine);
+  __syncthreads();
+  return visiting;
+}
+__device__ __forceinline__ float column_share_of_rows(const float* __restrict__ base, int sub, int rows, const unsigned long long* __restrict__ vmap) {
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* zero = &kZeroFloat;
+  for (int g = 0; g * (64 * kRowsPerSlot) < rows; ++g) {
+    const unsigned long long w = vmap[g];   // the 64 slots whose rows this group holds: uniform
+    if (w == 0) continue;
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (r + 32 * u < rows) v[u] += base[(size_t)(r + 32 * u) * kRow];
+    for (int u = 0; u < 8; ++u) {
+      const int in_group = sub + 32 * u;
+      const int r = g * (64 * kRowsPerSlot) + in_group;
+      const bool take = r < rows && ((w >> (in_group / kRowsPerSlot)) & 1ull);
+      const float* p = take ? base + (size_t)r * kRow : zero;
+      v[u] += *p;
+    }
+  }
   return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
+static_assert(64 * kRowsPerSlot == 8 * 32, "a group of 64 slots must be the 256 rows one pass of the 32 x 8 partial sums covers");
 
 // Both stages in one launch for the batched loop with an all-reduce hook: block k (1024 threads) sums keyframe k's
 // rows coalesced in the same fixed order as pose_reduce_solve_kernel and writes the coefficient row that goes through
 // the exchange (count as two exact 16-bit halves, as above).  Rows of converged keyframes are written as zeros, so
 // that repeated in-place all-reduces never grow stale values.
 __global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
-                                                               float* __restrict__ coeffs, const PoseState* __restrict__ states) {
+                                                               float* __restrict__ coeffs, const PoseState* __restrict__ states,
+                                                               const uint32_t* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
   const int k = blockIdx.x;
   if (states != nullptr && states[k].converged) {
     if (threadIdx.x < kRow) coeffs[(size_t)k * kRow + threadIdx.x] = 0.f;
     return;
   }
   __shared__ float sm[32][kRow];
+  extern __shared__ unsigned long long vmap[];   // visit_map_bytes(slots)
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf);   // the count column: <= 256 per row, exact in fp32 up to 65k rows
+  const int slots = rows_per_kf / kRowsPerSlot;
+  const uint32_t visiting = build_visit_map(vis + (size_t)(k / kfs_per_block) * slots, (uint32_t)(k % kfs_per_block), slots, vmap);
+  if (stats != nullptr && threadIdx.x == 0) { atomicAdd(&stats[0], (unsigned long long)slots); atomicAdd(&stats[1], (unsigned long long)visiting); }
+  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf, vmap);   // the count column: <= 256 per row, exact in fp32 up to 65k rows
   __syncthreads();
   if (threadIdx.x >= kRow) return;
   if (col == kRowCount) {
@@ -519,14 +565,19 @@ __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count
 constexpr int kReduceSolveThreads = 1024;
 __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                                PoseState* __restrict__ states, KfDev* __restrict__ kfs,
-                                                                               int* __restrict__ active_count, int* __restrict__ next_active_count) {
+                                                                               int* __restrict__ active_count, int* __restrict__ next_active_count,
+                                                                               const uint32_t* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
   const int k = blockIdx.x;
   if (k == 0 && threadIdx.x == 0) *next_active_count = 0;   // the next iteration's counter (last read four iterations ago)
   if (states[k].converged) return;   // uniform
   __shared__ float sm[32][kRow];
   __shared__ float row[kRow];
+  extern __shared__ unsigned long long vmap[];   // visit_map_bytes(slots)
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf);
+  const int slots = rows_per_kf / kRowsPerSlot;
+  const uint32_t visiting = build_visit_map(vis + (size_t)(k / kfs_per_block) * slots, (uint32_t)(k % kfs_per_block), slots, vmap);
+  if (stats != nullptr && threadIdx.x == 0) { atomicAdd(&stats[0], (unsigned long long)slots); atomicAdd(&stats[1], (unsigned long long)visiting); }
+  sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf, vmap);
   __syncthreads();
   if (threadIdx.x < 27) {
     float total = 0.f;

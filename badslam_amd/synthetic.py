@@ -320,7 +320,9 @@ class TorchStack(DeviceStack):
 
     def __init__(self, num_keyframes, device, width=640, height=480, cell=4, seed=0xBAD51A4, fx=525.0, fy=525.0, cx=320.0, cy=240.0,
                  raw_to_float_depth=1.0 / 5000, baseline_fx=40.0, translation_range=None, rotation_range=None, plane_count=20,
-                 surfel_noise=0.002, kind="dense"):
+                 surfel_noise=0.002, kind="dense", border_valid=False):
+        """border_valid: the outermost pixel rows / columns carry measurements too (the default leaves them empty, as the
+        reference's preprocessing does for normals); tests of the image-bound handling use it."""
         import torch
         self.torch = torch
         self.device = device
@@ -377,7 +379,8 @@ class TorchStack(DeviceStack):
             best, which = tt.min(dim=2)
             bestn = P[which]
             valid = torch.isfinite(best) & (best < 6.0)
-            valid[0, :] = False; valid[-1, :] = False; valid[:, 0] = False; valid[:, -1] = False
+            if not border_valid:
+                valid[0, :] = False; valid[-1, :] = False; valid[:, 0] = False; valid[:, -1] = False
             d = torch.where(valid, best / float(raw_to_float_depth) + 0.5, torch.full_like(best, 65535.0)).to(torch.int64)
             valid &= d < 32768
             d = torch.where(valid, d, torch.full_like(d, 65535))

@@ -178,6 +178,16 @@ int bslam_invalidate_keyframe_cache(bslam_context* ctx);
  * index order (A/B measurements, bit-for-bit comparisons between entry points). */
 int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
 
+/* Block-level frustum culling (default on).  With the per-surfel work order the surfels of a workgroup are a compact blob; a
+ * workgroup skips every keyframe into whose image no point of its surfels' bounding box can project (decided once per
+ * workgroup and keyframe, exactly conservatively -- no pair that passes the reference's projection test
+ * (ProjectSurfelToImage, BS/util.cuh:86-99) is ever skipped -- so every output is bit-identical with and without it).  The
+ * reference spends a thread on every (surfel, keyframe) pair (BS/kernel_opt_pose.cu:263-275).  0 = visit every pair. */
+int bslam_set_culling(bslam_context* ctx, int enable);
+/* (work slot, keyframe) pairs the pose kernel's launches tested / skipped since the last call (HOST out; counted while
+ * bslam_profile_enable is on; synchronises the device and resets the counters). */
+int bslam_debug_cull_stats(bslam_context* ctx, uint64_t* tested, uint64_t* culled);
+
 /* Kernel timing for the roofline line of bench.py (the role of the reference's cudaEvent
  * pairs, BS/direct_ba.h:513-532): while enabled, every launch of the dominant kernel of a
  * call (the surfel x keyframe pass) is bracketed by HIP events on the launch stream.
@@ -324,9 +334,6 @@ int bslam_debug_association(
  * `keyframes_per_launch` keyframes, with the per-surfel sums carried in library scratch (results are bit-identical to a
  * single launch).  -1 = the library's default (one launch); 0 = always one launch. */
 int bslam_set_geometry_keyframe_chunk(bslam_context* ctx, int keyframes_per_launch);
-/* 1: the photometric geometry iteration runs as ONE launch of the one-surfel-per-thread kernel over the whole keyframe list
- * (the round-1 form; bit-identical results, kept for A/B measurements and as the parity reference of the chunked form). */
-int bslam_set_geometry_descriptor_legacy(bslam_context* ctx, int enable);
 
 /* Replaces AssignColorsCUDA (BS/kernels.h:301-308, BS/kernel_assign_colors.cc:40-80, .cu:42-125): every surfel's
  * colour row becomes the mean of the bilinearly filtered uchar4 colours of the pixels it is associated with over ALL

@@ -1,0 +1,148 @@
+"""-m gpu: block-level frustum culling (csrc/device_math.hpp: box_outside_frustum) must be exactly conservative.
+
+A workgroup skips a keyframe when no point of its surfels' bounding box can project into the image.  If the test ever skipped a
+pair that passes the projection test, a residual would go missing; so every output -- integer ones and float sums alike -- has to
+be bit-identical with culling on and off.  Checked on the three synthetic stacks of SURVEY.md 8(d) (dense: little to cull;
+survey ranges and trajectory: most pairs are out of view), with keyframe images whose border pixels carry measurements (so
+that pairs on the very edge of the image do associate) and at poses shifted by fractions of a pixel, which moves thousands of
+surfels across the image bounds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import badslam_amd
+from badslam_amd import abi, synthetic
+
+pytestmark = pytest.mark.gpu
+P = C.POINTER
+
+
+class Runner:
+    def __init__(self, dev, use_desc):
+        import torch
+        self.torch, self.dev, self.use_desc = torch, dev, use_desc
+        self.L = badslam_amd.lib()
+        self.ctx = badslam_amd.Context(0)
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.K = dev.stack.K
+        self.cam = dev.stack.camera
+
+    def views(self, xis=None):
+        kfs = self.dev.keyframe_views()
+        if xis is not None:
+            for k in range(self.K):
+                _, M, Rg = self.dev.stack.pose(k, xis[k])
+                kfs[k].frame_T_global, kfs[k].global_R_frame = M, Rg
+        return kfs
+
+    def culling(self, on):
+        badslam_amd.check(self.L.bslam_set_culling(self.ctx.handle, int(on)))
+
+    def coeffs(self, kfs):
+        dp, sb = self.dev.depth_params(), self.dev.buf(self.dev.surfels)
+        Hb = np.zeros((self.K, 27), np.float32)
+        counts = np.zeros(self.K, np.uint32)
+        badslam_amd.check(self.L.bslam_accumulate_pose_coeffs_batched(
+            self.ctx.handle, self.stream, 1, int(self.use_desc), C.byref(self.cam), C.byref(self.cam), C.byref(dp), self.K, kfs, self.dev.surfels_size,
+            C.byref(sb), Hb.ctypes.data_as(P(C.c_float)), counts.ctypes.data_as(P(C.c_uint32))))
+        return Hb, counts
+
+    def geometry(self, kfs):
+        dp, sb, ab = self.dev.depth_params(), self.dev.buf(self.dev.surfels), self.dev.buf(self.dev.active)
+        badslam_amd.check(self.L.bslam_optimize_geometry_iteration(self.ctx.handle, self.stream, 1, int(self.use_desc), C.byref(self.cam), C.byref(self.cam),
+                                                                   C.byref(dp), self.K, kfs, self.dev.surfels_size, C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+
+    def normals(self, kfs):
+        dp, sb, ab = self.dev.depth_params(), self.dev.buf(self.dev.surfels), self.dev.buf(self.dev.active)
+        badslam_amd.check(self.L.bslam_update_surfel_normals(self.ctx.handle, self.stream, C.byref(self.cam), C.byref(dp), self.K, kfs, self.dev.surfels_size,
+                                                             C.byref(sb), C.byref(ab)))
+        self.torch.cuda.synchronize()
+
+    def poses(self, kfs, inits, iterations):
+        dp, sb = self.dev.depth_params(), self.dev.buf(self.dev.surfels)
+        poses = (abi.SE3f * self.K)()
+        C.memmove(poses, inits, C.sizeof(poses))
+        iters, conv = (C.c_int32 * self.K)(), (C.c_int32 * self.K)()
+        badslam_amd.check(self.L.bslam_estimate_frame_poses_batched(self.ctx.handle, self.stream, 1, int(self.use_desc), C.byref(self.cam), C.byref(self.cam),
+                                                                    C.byref(dp), self.K, kfs, self.dev.surfels_size, C.byref(sb), iterations, poses, iters, conv,
+                                                                    C.cast(None, abi.ALLREDUCE_FN), None))
+        return np.array([[*p.q, *p.t] for p in poses], np.float32), list(iters)
+
+    def cull_stats(self):
+        t, c = C.c_uint64(), C.c_uint64()
+        badslam_amd.check(self.L.bslam_debug_cull_stats(self.ctx.handle, C.byref(t), C.byref(c)))
+        return t.value, c.value
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("kind,K,use_desc", [("dense", 8, True), ("survey", 12, False), ("survey", 12, True),
+                                             ("trajectory", 40, False), ("trajectory", 40, True)])
+def test_outputs_are_bit_identical_with_and_without_culling(kind, K, use_desc):
+    import torch
+    dev = synthetic.TorchStack(K, "cuda:0", kind=kind, border_valid=True)
+    assert dev.surfels_size >= 64 * 256 and K >= 4          # the per-surfel work order (and with it the culling) is in use
+    run = Runner(dev, use_desc)
+    start = dev.surfels.clone()
+    rng = np.random.default_rng(11)
+    pix = 1.0 / 525.0                                        # one pixel, in radians
+    pose_sets = [None]
+    for scale in (0.3, 1.0, 2.5):                           # sub-pixel and few-pixel shifts: surfels cross the image bounds
+        pose_sets.append([np.concatenate([rng.uniform(-1, 1, 3) * 0.002 * scale, rng.uniform(-1, 1, 3) * pix * scale]) for _ in range(K)])
+    inits = (abi.SE3f * K)()
+    for k in range(K):
+        inits[k] = dev.stack.pose(k, np.concatenate([rng.choice([-1, 1], 3) * 0.005, rng.choice([-1, 1], 3) * 0.001]))[0]
+    out = {}
+    for on in (1, 0):
+        run.culling(on)
+        dev.surfels.copy_(start)
+        res = []
+        badslam_amd.check(run.L.bslam_profile_enable(run.ctx.handle, 1))
+        run.cull_stats()
+        for xis in pose_sets:
+            Hb, counts = run.coeffs(run.views(xis))
+            res += [bits(Hb), counts]
+        tested, culled = run.cull_stats()
+        badslam_amd.check(run.L.bslam_profile_enable(run.ctx.handle, 0))
+        run.normals(run.views(pose_sets[1]))
+        res.append(bits(dev.surfels[:8].cpu().numpy()))
+        run.geometry(run.views(pose_sets[2]))                # with descriptors: two iterations, so that the second one sees fitted descriptors
+        run.geometry(run.views())
+        res.append(bits(dev.surfels[:8].cpu().numpy()))
+        poses, iters = run.poses(run.views(), inits, 4)
+        res += [bits(poses), np.array(iters)]
+        out[on] = (res, tested, culled)
+    dev.surfels.copy_(start)
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a, b)
+    assert out[0][2] == 0 and out[0][1] > 0                  # culling off: every (slot, keyframe) pair visited
+    assert out[1][1] == out[0][1]
+    frac = out[1][2] / out[1][1]
+    counts = out[1][0][1]
+    assert counts.min() > 1000, counts.min()                 # the sums are not trivially empty
+    if kind == "trajectory":
+        assert frac > 0.6, frac                              # most of the room is out of view of a keyframe
+    if kind == "survey":
+        assert frac > 0.2, frac
+
+
+def test_deleted_and_far_surfels_do_not_break_the_boxes():
+    """NaN positions (deleted surfels) are ignored by the boxes, infinite or huge ones make a box that is never culled."""
+    import torch
+    K = 16
+    dev = synthetic.TorchStack(K, "cuda:0", kind="trajectory", border_valid=True)
+    run = Runner(dev, False)
+    n = dev.surfels_size
+    dev.surfels[0, torch.arange(0, n, 13, device="cuda:0")] = float("nan")
+    dev.surfels[1, torch.arange(5, n, 4099, device="cuda:0")] = float("inf")
+    dev.surfels[2, torch.arange(7, n, 5003, device="cuda:0")] = 3.0e38
+    out = {}
+    for on in (1, 0):
+        run.culling(on)
+        out[on] = run.coeffs(run.views())
+    assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(out[1][1], out[0][1])
+    assert np.isfinite(out[1][0]).all() and out[1][1].min() > 1000

@@ -470,9 +470,9 @@ def test_many_small_keyframes(oracle):
 
 
 def test_photometric_geometry_chunked_equals_single_launch(oracle):
-    """The photometric (position + descriptor) geometry iteration in its production shape -- several surfels per thread, resident grids,
-    keyframe chunks with the per-surfel sums carried in scratch -- is bit-identical to the one-launch one-surfel-per-thread kernel,
-    for a chunk size that divides the keyframe list unevenly, for the whole list in one chunk, and agrees with the oracle."""
+    """The photometric (position + descriptor) geometry iteration walked in keyframe chunks with the per-surfel sums carried in
+    scratch is bit-identical to one launch over the whole list -- for chunk sizes that divide the keyframe list unevenly, with
+    and without the block-level frustum culling -- and agrees with the oracle."""
     from tests import gpu_util
     cam = bso.make_camera(131.25, 131.25, 80.0, 60.0, 160, 120)
     scene = scenes.synthetic_scene(37, seed=17, width=160, height=120, camera=cam, use_depth_residuals=True, use_descriptor_residuals=True)
@@ -483,13 +483,13 @@ def test_photometric_geometry_chunked_equals_single_launch(oracle):
     start = hip.d.surfels.clone()
     L, h = hip.L, hip.ctx.handle
     results = {}
-    for name, legacy, chunk in (("legacy", 1, 0), ("chunk16", 0, 16), ("chunk5", 0, 5), ("one chunk", 0, 0)):
+    for name, culling, chunk in (("legacy", 0, 0), ("chunk16", 1, 16), ("chunk5", 0, 5), ("one chunk", 1, 0)):
         hip.d.surfels.copy_(start)
-        badslam_amd.check(L.bslam_set_geometry_descriptor_legacy(h, legacy))
+        badslam_amd.check(L.bslam_set_culling(h, culling))
         badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, chunk))
         hip.optimize_geometry_iteration()
         results[name] = hip.d.surfels_np()[:8, :n].copy()
-    badslam_amd.check(L.bslam_set_geometry_descriptor_legacy(h, 0))
+    badslam_amd.check(L.bslam_set_culling(h, 1))
     badslam_amd.check(L.bslam_set_geometry_keyframe_chunk(h, -1))
     for name in ("chunk16", "chunk5", "one chunk"):
         assert np.array_equal(results[name].view(np.uint32), results["legacy"].view(np.uint32)), name
@@ -581,3 +581,47 @@ def test_photometric_gauss_newton_converges_alike_in_both_texture_modes(oracle):
         results[name] = (iters, np.stack([bso.se3_to_np(p) for p in poses]))
     assert results["fixed"][0] == results["exact"][0]
     assert np.abs(results["fixed"][1] - results["exact"][1]).max() < 1e-6
+
+
+def test_work_order_caches_survive_interleaved_buffers_and_sizes(multi, oracle):
+    """One context, two surfel buffers of different sizes, calls with < 4 keyframes (granule order) interleaved with calls with
+    >= 4 keyframes (per-surfel order), and one buffer going S1 -> S2 -> S1: every call must give what a fresh context gives.
+    (The two caches of make_schedule used to share scratch: building the per-surfel order of one buffer overwrote the cached
+    granule order of another while leaving its key valid.)"""
+    from tests import gpu_util
+    sceneA, _ = multi                                                                    # 6 keyframes, 115 200 surfels
+    sceneB = scenes.synthetic_scene(4, seed=11, use_depth_residuals=True, use_descriptor_residuals=True)
+    assert sceneA.surfels_size >= 64 * 256 and sceneB.surfels_size >= 64 * 256 and sceneA.surfels_size != sceneB.surfels_size
+    fresh = lambda scene: gpu_util.Hip(scene.to_device())
+    refA1 = fresh(sceneA).accumulate_pose(0)
+    refA_b = fresh(sceneA).accumulate_pose_batched()
+    refB_b = fresh(sceneB).accumulate_pose_batched()
+    refB1 = fresh(sceneB).accumulate_pose(1)
+    ctx = badslam_amd.Context(0)
+    A, B = gpu_util.Hip(sceneA.to_device(), ctx), gpu_util.Hip(sceneB.to_device(), ctx)
+
+    def same(got, ref):
+        if isinstance(ref, dict):
+            return got["count"] == ref["count"] and np.array_equal(got["H"].view(np.uint32), ref["H"].view(np.uint32)) and np.array_equal(got["b"].view(np.uint32), ref["b"].view(np.uint32))
+        return np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(got[1], ref[1])
+
+    assert same(A.accumulate_pose(0), refA1)          # granule order of A cached
+    assert same(B.accumulate_pose_batched(), refB_b)  # per-surfel order of B (other granule count) built
+    assert same(A.accumulate_pose(0), refA1)          # A's cached granule order is still A's
+    assert same(A.accumulate_pose_batched(), refA_b)
+    assert same(B.accumulate_pose(1), refB1)
+    assert same(A.accumulate_pose(0), refA1)
+    assert same(B.accumulate_pose_batched(), refB_b)
+    # one buffer, size S1 -> S2 -> S1
+    full = A.d.surfels_size
+    refA_half = None
+    for size in (full, (full // 2) & ~255, full):
+        A.d.surfels_size = size
+        got1, gotb = A.accumulate_pose(0), A.accumulate_pose_batched()
+        if size == full:
+            assert same(got1, refA1) and same(gotb, refA_b)
+        else:
+            h = fresh(sceneA)
+            h.d.surfels_size = size
+            assert same(got1, h.accumulate_pose(0)) and same(gotb, h.accumulate_pose_batched())
+    A.d.surfels_size = full
