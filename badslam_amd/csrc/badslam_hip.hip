@@ -533,6 +533,7 @@ int bslam_create(int device, bslam_context** out_ctx) {
   int rc = ctx->misc.reserve(256);
   if (rc) { delete ctx; return rc; }
   if (hipMemset(ctx->misc.ptr, 0, 256) != hipSuccess) { delete ctx; return fail(BSLAM_ERR_HIP, "hipMemset failed"); }
+  if (const char* e = getenv("BSLAM_CULLING")) ctx->culling = atoi(e) != 0;   // A/B runs of whole programs (bslam_set_culling otherwise)
   *out_ctx = ctx;
   return BSLAM_OK;
 }
@@ -1017,10 +1018,17 @@ int bslam_update_surfel_activation(
   int rc = geometry_common(ctx, stream, nullptr, depth_camera, depth_params, false, keyframe_count, keyframes, surfels_size, surfels, active_surfels);
   if (rc) return rc;
   const CamConsts c = make_cam_consts(ctx, nullptr, depth_camera, depth_params);
-  // granule order, not the per-surfel one: a surfel stops at its first associated keyframe (about 3 of K visited), which
-  // does not pay for a sorted copy of the rows
+  // A surfel stops at its first associated keyframe.  On a stack where every keyframe sees everything that is about 3 of K
+  // visits, which does not pay for a sorted copy of the rows: granule order.  On a trajectory the first keyframes of the list
+  // do not see the surfel at all and the walk is long; from kActivationPermMinKeyframes keyframes on the pass therefore runs
+  // in the per-surfel order with the block-level frustum culling, which skips the keyframes a work slot cannot see
+  // (K = 300 trajectory stack: 1.67 ms -> see DESIGN.md; dense stack: unchanged within noise).
+#ifndef BSLAM_ACTIVATION_PERM_MIN_KEYFRAMES
+#define BSLAM_ACTIVATION_PERM_MIN_KEYFRAMES 64
+#endif
   SurfelWork work;
-  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, 1, 1, &work, false))) return rc;
+  const bool per_surfel_order = ctx->culling && keyframe_count >= BSLAM_ACTIVATION_PERM_MIN_KEYFRAMES;
+  if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, 1, per_surfel_order ? keyframe_count : 1, &work, false))) return rc;
   const Schedule sc = work.sc;
   {
     ProfScope prof(ctx, stream, BSLAM_PROF_ACTIVATION);

@@ -792,33 +792,45 @@ __device__ __forceinline__ bool box_outside_frustum(const CamConsts& c, const fl
 }
 
 // Keyframes k0 + lane, lane = 0 .. 63, below k_end: bit `lane` of the result is set when the keyframe has to be visited
-// (`wanted` is the caller's own per-lane condition -- not converged, not inactive -- and `bounds` == nullptr means no
-// culling).  Uniform across the wave.
-__device__ __forceinline__ unsigned long long keyframes_to_visit(const CamConsts& c, const KfDev* __restrict__ kfs, int k0, int k_end, bool culling,
-                                                                 const SlotBox& box, bool wanted) {
+// (`wanted` is the caller's own per-lane condition -- not converged, not inactive; sc.bounds == nullptr means no culling).
+// Uniform across the wave.  The slot's box is rebuilt from the granule boxes on every call (a few uniform loads per 64
+// keyframes) rather than kept live across the caller's keyframe loop, where it would cost registers.
+__device__ __forceinline__ unsigned long long keyframes_to_visit(const CamConsts& c, const KfDev* __restrict__ kfs, int k0, int k_end, const Schedule& sc,
+                                                                 uint32_t slot, int R, bool wanted) {
   const int k = k0 + (int)(threadIdx.x & 63u);
   bool visit = k < k_end && wanted;
-  if (visit && culling) {
-    float T[12];
+  if (sc.bounds != nullptr) {
+    uint32_t s_ = slot;
+    asm volatile("" : "+s"(s_));   // keeps the box's loads inside the caller's loop over keyframe batches
+    const SlotBox box = slot_box(sc.bounds, sc.granules, s_, R);
+    if (visit) {
+      float T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = kfs[k].frame_T_global.m[i];
-    visit = !box_outside_frustum(c, T, box);
+      for (int i = 0; i < 12; ++i) T[i] = kfs[k].frame_T_global.m[i];
+      visit = !box_outside_frustum(c, T, box);
+    }
   }
   return __ballot(visit);
 }
 
-// Walks the keyframes of [k_begin, k_end) that are not INACTIVE and that the slot's box reaches, in list order (64 keyframes
-// are decided at a time, one per lane): inside the body, `K_` is the keyframe's index.  Needs c, kfs, sc and box in scope.
+// Walks the keyframes of [k_begin, k_end) that the slot's box reaches, in list order (64 keyframes are decided at a time, one
+// per lane): inside the body, `K_` is the keyframe's index.  Needs c, kfs, sc and slot in scope; SLOT_R_ = granules per work slot.  WANTED_ is the caller's
+// per-lane condition on keyframe k0_ + lane (evaluated only for lanes below k_end by the helpers below).
 __device__ __forceinline__ bool keyframe_not_inactive(const KfDev* __restrict__ kfs, int k0, int k_end) {
   const int k = k0 + (int)(threadIdx.x & 63u);
   return k < k_end && kfs[k].activation != BSLAM_KF_INACTIVE;
 }
-#define BSLAM_FOR_VISITED_KEYFRAMES(K_, k_begin, k_end)                                                                        \
+__device__ __forceinline__ bool keyframe_active(const KfDev* __restrict__ kfs, int k0, int k_end) {
+  const int k = k0 + (int)(threadIdx.x & 63u);
+  return k < k_end && kfs[k].activation == BSLAM_KF_ACTIVE;
+}
+#define BSLAM_FOR_VISITED_KEYFRAMES_IF(K_, k_begin, k_end, SLOT_R_, WANTED_)                                                           \
   for (int k0_ = (k_begin); k0_ < (k_end); k0_ += 64)                                                                          \
-    for (unsigned long long todo_ = keyframes_to_visit(c, kfs, k0_, (k_end), sc.bounds != nullptr, box,                        \
-                                                       keyframe_not_inactive(kfs, k0_, (k_end)));                              \
+    for (unsigned long long todo_ = keyframes_to_visit(c, kfs, k0_, (k_end), sc, slot, (SLOT_R_), (WANTED_));                  \
          todo_ != 0; todo_ &= todo_ - 1)                                                                                       \
       if (const int K_ = k0_ + __builtin_ctzll(todo_); true)
+// ... those that are not INACTIVE (the geometry passes, BS/kernel_opt_geometry.cc:115-118)
+#define BSLAM_FOR_VISITED_KEYFRAMES(K_, k_begin, k_end, SLOT_R_) BSLAM_FOR_VISITED_KEYFRAMES_IF(K_, k_begin, k_end, SLOT_R_, keyframe_not_inactive(kfs, k0_, (k_end)))
 
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions

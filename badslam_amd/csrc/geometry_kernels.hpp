@@ -98,21 +98,22 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const uint32_t i = surfel_of_slot(sc, slot, 0, 1);
   uint32_t visited = 0, activated = 0;
-  if (!kCount && i >= s.size) return;
-  if (i < s.size) {
-    const uint32_t col = column_of(s, i);
-    uint8_t flag = s.active[col] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG;
-    const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
-    const f3 gn = unpack_normal(s.normal[i]);
-    for (int k = 0; k < kf_count; ++k) {
-      const KfDev kf = kfs[k];
-      if (kf.activation != BSLAM_KF_ACTIVE) continue;
+  const bool valid = i < s.size;
+  const uint32_t j = valid ? i : 0;
+  const uint32_t col = column_of(s, j);
+  uint8_t flag = valid ? (s.active[col] & (uint8_t)~BSLAM_SURFEL_ACTIVE_FLAG) : 0;
+  const f3 gp = mk3(s.x[j], s.y[j], s.z[j]);
+  const f3 gn = unpack_normal(s.normal[j]);
+  bool searching = valid;   // until the surfel's first associated ACTIVE keyframe
+  BSLAM_FOR_VISITED_KEYFRAMES_IF(k, 0, kf_count, 1, keyframe_active(kfs, k0_, kf_count)) {
+    if (!__any(searching)) break;   // uniform; the outer batch loop ends below
+    if (searching) {
       if (kCount) visited += 1;
       Proj p;
-      if (project_and_associate(c, kf, gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; activated = 1; break; }
+      if (project_and_associate(c, kfs[k], gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; activated = 1; searching = false; }
     }
-    s.active[col] = flag;
   }
+  if (valid) s.active[col] = flag;
   if (kCount) {
     __shared__ uint32_t sm[2][4];
     visited = wave_sum_u32(visited);
@@ -369,13 +370,11 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
   }
-  SlotBox box;
-  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
   {
     float sx[R], sy[R], sz[R], cnt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
-    BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count) {
+    BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
       const KfDev kf = kfs[k];
       const float* Rm = kf.global_R_frame;
 #pragma unroll
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
   float H[R], b[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
-  BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count) {
+  BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
     const KfDev kf = kfs[k];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -455,9 +454,7 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
       if (kPass == 0) { a2[r] = acc[(size_t)2 * acc_pitch + j]; a3[r] = acc[(size_t)3 * acc_pitch + j]; }
     }
   }
-  SlotBox box;
-  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
-  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end) {
+  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end, R) {
     const KfDev kf = kfs[k];
     const float* Rm = kf.global_R_frame;
 #pragma unroll
@@ -537,9 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
 #pragma unroll
     for (int q = 0; q < kAcc; ++q) a[r][q] = (!first_chunk && on[r]) ? acc[(size_t)q * acc_pitch + j] : 0.f;
   }
-  SlotBox box;
-  if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, R);
-  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end) {
+  BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end, R) {
     const KfDev kf = kfs[k];
     const float* Rm = kf.global_R_frame;
 #pragma unroll

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
 #pragma unroll
   for (int i = 0; i < kIntrRow; ++i) acc[i] = 0.f;
 
-  for (int k = 0; k < kf_count; ++k) {
+  BSLAM_FOR_VISITED_KEYFRAMES_IF(k, 0, kf_count, kIntrR, true) {
     const KfDev kf = kfs[k];
 #pragma unroll
     for (int r = 0; r < kIntrR; ++r) {

@@ -371,27 +371,33 @@ __global__ __launch_bounds__(256) void create_append_kernel(CamConsts c, KfImage
 // Work order as in the BA kernels (make_schedule): block -> slot of an XCD-contiguous range, position -> surfel column through
 // the per-surfel Morton permutation `perm` (nullptr: identity).  K = 300, S = 5.76 M: 30.7 ms -> about 5 ms (PCG BA iteration 370 -> 344 ms).
 __global__ __launch_bounds__(256) void delete_and_update_radii_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int min_observation_count,
-                                                                     uint32_t size, Schedule sc, const uint32_t* __restrict__ perm, SurfelRowsAll s,
+                                                                     uint32_t size, Schedule sc, const uint32_t* __restrict__ perm, SurfelRows sorted, SurfelRowsAll s,
                                                                      uint32_t* __restrict__ deleted_count) {
+  // `sorted`: with a per-surfel order, the library's sorted copy of position and normal (position `at` of it is the caller's
+  // column perm[at]); the keyframes a work slot cannot see are skipped (block-level frustum culling: a surfel that does not
+  // project into a keyframe is neither an observation nor a free-space violation there)
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const uint32_t at = surfel_of_slot(sc, slot, 0, 1);
   const uint32_t i = (perm != nullptr && at < size) ? perm[at] : at;
   bool deleted = false;
-  if (i < size) {
-    const f3 gp = mk3(s.x[i], s.y[i], s.z[i]);
-    const f3 gn = unpack_normal(s.normal[i]);
-    float observations = 0.f, violations = 0.f, min_radius = __uint_as_float(0x7f800000u);
-    for (int k = 0; k < kf_count; ++k) {
-      int px, py;
-      bool fsv = false;
-      if (associate_records_fs(c, kfs[k], gp, gn, &px, &py, &fsv)) {
-        observations += 1.f;
-        min_radius = fminf(min_radius, half_bits_to_float(img_u16(kfs[k].radius, kfs[k].radius_pitch, py, px)));
-      } else if (fsv) {
-        violations += 1.f;
-      }
+  const bool valid = i < size;
+  const uint32_t j = valid ? at : 0;
+  const f3 gp = mk3(sorted.x[j], sorted.y[j], sorted.z[j]);
+  const f3 gn = unpack_normal(sorted.normal[j]);
+  float observations = 0.f, violations = 0.f, min_radius = __uint_as_float(0x7f800000u);
+  BSLAM_FOR_VISITED_KEYFRAMES_IF(k, 0, kf_count, 1, true) {
+    int px, py;
+    bool fsv = false;
+    if (!valid) continue;
+    if (associate_records_fs(c, kfs[k], gp, gn, &px, &py, &fsv)) {
+      observations += 1.f;
+      min_radius = fminf(min_radius, half_bits_to_float(img_u16(kfs[k].radius, kfs[k].radius_pitch, py, px)));
+    } else if (fsv) {
+      violations += 1.f;
     }
+  }
+  if (valid) {
     if (observations < (float)min_observation_count || violations > observations) {
       if (__float_as_uint(gp.x) != kNanBits) { s.x[i] = __uint_as_float(kNanBits); deleted = true; }
     } else {

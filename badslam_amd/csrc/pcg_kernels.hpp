@@ -40,6 +40,31 @@ constexpr int kPcgR = BSLAM_PCG_R;
 // reduction (6 - 12 wave sums + a barrier) over twice as many pairs
 constexpr int pcg_surfels_per_thread(bool desc, bool intr) { return (!desc && !intr) ? BSLAM_PCG_R_GEO : kPcgR; }
 constexpr int kPcgPoseRow = 12;    // init: r[6], M[6];  step1: g[6] (+6 unused)
+// Per-keyframe pose rows of a workgroup: every wave drops its wave sums into an LDS stash and moves on; after kPcgGroup visited
+// keyframes ONE barrier lets the block add the four waves' entries -- ((w0 + w1) + w2) + w3, the order of the former
+// per-keyframe reduction: same bits -- and store one row per (keyframe, work slot).  Two stashes alternate, so a wave that runs
+// ahead into the next group never overwrites entries that are still being added (it cannot get two groups ahead: the barrier).
+constexpr int kPcgGroup = 16;
+struct PcgRowStash {
+  float v[2][kPcgGroup][4][kPcgPoseRow];
+  int kf[2][kPcgGroup];
+};
+// Adds up and stores the `n` stashed keyframes of buffer `buf` (all threads call; contains the group's one barrier).
+__device__ __forceinline__ void pcg_flush_rows(PcgRowStash& st, int buf, int n, float* __restrict__ partial_pose, uint32_t slots, int tile) {
+  __syncthreads();
+  const int j = threadIdx.x / kPcgPoseRow, col = threadIdx.x - j * kPcgPoseRow;
+  if (j < n)
+    partial_pose[((size_t)st.kf[buf][j] * slots + tile) * kPcgPoseRow + col] = ((st.v[buf][j][0][col] + st.v[buf][j][1][col]) + st.v[buf][j][2][col]) + st.v[buf][j][3][col];
+}
+static_assert(kPcgGroup * kPcgPoseRow <= kPcgThreads, "one thread per stashed value");
+// Zero rows for the keyframes of the batch [k0, k0 + 64) that the workgroup does not visit (frustum culling): the row sums read
+// every (keyframe, work slot) row.
+__device__ __forceinline__ void pcg_zero_rows(unsigned long long visited, int k0, int k_end, float* __restrict__ partial_pose, uint32_t slots, int tile) {
+  for (int i = threadIdx.x; i < 64 * kPcgPoseRow; i += kPcgThreads) {
+    const int b = i / kPcgPoseRow, k = k0 + b;
+    if (k < k_end && !((visited >> b) & 1ull)) partial_pose[((size_t)k * slots + tile) * kPcgPoseRow + (i - b * kPcgPoseRow)] = 0.f;
+  }
+}
 constexpr int kPcgGlobRow = 20;    // init: depth intr r[5], M[5], colour r[4], M[4]; step1: alpha_d, g depth[5], g colour[4]
 
 struct PcgParams {
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float red[2][4][16];
+  __shared__ PcgRowStash stash;
   __shared__ float redg[4][32];
 
   f3 gp[R], gn[R];
@@ -179,8 +204,13 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 #pragma unroll
   for (int i = 0; i < kPcgGlobRow; ++i) glob[i] = 0.f;
 
-  int parity = 0;
-  for (int k = 0; k < kf_count; ++k) {
+  int stashed = 0;   // keyframes in the current stash (uniform)
+  int buf = 0;
+  for (int k0 = 0; k0 < kf_count; k0 += 64) {
+  unsigned long long todo = keyframes_to_visit(c, kfs, k0, kf_count, sc, slot, R, true);
+  if (P.optimize_poses && sc.bounds != nullptr) pcg_zero_rows(todo, k0, kf_count, partial_pose, sc.slots, tile);
+  for (; todo != 0; todo &= todo - 1) {
+    const int k = k0 + __builtin_ctzll(todo);
     const KfDev kf = kfs[k];
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
@@ -292,15 +322,14 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = wave_sum(pose[i]);
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < kPcgPoseRow; ++i) red[parity][wave][i] = pose[i];
+        for (int i = 0; i < kPcgPoseRow; ++i) stash.v[buf][stashed][wave][i] = pose[i];
+        if (wave == 0) stash.kf[buf][stashed] = k;
       }
-      __syncthreads();
-      if (threadIdx.x < kPcgPoseRow)
-        partial_pose[((size_t)k * sc.slots + tile) * kPcgPoseRow + threadIdx.x] =
-            ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x];
-      parity ^= 1;
+      if (++stashed == kPcgGroup) { pcg_flush_rows(stash, buf, stashed, partial_pose, sc.slots, tile); stashed = 0; buf ^= 1; }
     }
   }
+  }
+  if (stashed) pcg_flush_rows(stash, buf, stashed, partial_pose, sc.slots, tile);
 
   if (P.optimize_geometry) {
 #pragma unroll
@@ -408,7 +437,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
   const int tile = (int)slot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float red[2][4][16];
+  __shared__ PcgRowStash stash;
   __shared__ float redg[4][32];
 
   f3 gp[R], gn[R];
@@ -447,8 +476,13 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (kIntr && P.optimize_depth_intr) for (int j = 0; j < 5; ++j) pdi[j] = P.p[P.depth_intr_start + j];
   if (kIntr && P.optimize_color_intr) for (int j = 0; j < 4; ++j) pci[j] = P.p[P.color_intr_start + j];
 
-  int parity = 0;
-  for (int k = 0; k < kf_count; ++k) {
+  int stashed = 0;   // keyframes in the current stash (uniform)
+  int buf = 0;
+  for (int k0 = 0; k0 < kf_count; k0 += 64) {
+  unsigned long long todo = keyframes_to_visit(c, kfs, k0, kf_count, sc, slot, R, true);
+  if (P.optimize_poses && sc.bounds != nullptr) pcg_zero_rows(todo, k0, kf_count, partial_pose, sc.slots, tile);
+  for (; todo != 0; todo &= todo - 1) {
+    const int k = k0 + __builtin_ctzll(todo);
     const KfDev kf = kfs[k];
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
@@ -572,15 +606,14 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       for (int i = 0; i < 6; ++i) pose[i] = wave_sum(pose[i]);
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) red[parity][wave][i] = pose[i];
+        for (int i = 0; i < kPcgPoseRow; ++i) stash.v[buf][stashed][wave][i] = (i < 6) ? pose[i] : 0.f;
+        if (wave == 0) stash.kf[buf][stashed] = k;
       }
-      __syncthreads();
-      if (threadIdx.x < kPcgPoseRow)
-        partial_pose[((size_t)k * sc.slots + tile) * kPcgPoseRow + threadIdx.x] = (threadIdx.x < 6)
-            ? ((red[parity][0][threadIdx.x] + red[parity][1][threadIdx.x]) + red[parity][2][threadIdx.x]) + red[parity][3][threadIdx.x] : 0.f;
-      parity ^= 1;
+      if (++stashed == kPcgGroup) { pcg_flush_rows(stash, buf, stashed, partial_pose, sc.slots, tile); stashed = 0; buf ^= 1; }
     }
   }
+  }
+  if (stashed) pcg_flush_rows(stash, buf, stashed, partial_pose, sc.slots, tile);
 
   if (P.optimize_geometry) {
 #pragma unroll

@@ -116,9 +116,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   {
     const int k = kf_begin + lane;
     const bool wanted = states == nullptr || (k < kf_end && !states[k].converged);
-    SlotBox box;
-    if (sc.bounds != nullptr) box = slot_box(sc.bounds, sc.granules, slot, kPoseR);
-    todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc.bounds != nullptr, box, wanted);
+    todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc, slot, kPoseR, wanted);
   }
   if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = (uint32_t)todo;
   if (todo == 0) return;   // leaves before touching the surfels

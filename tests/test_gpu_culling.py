@@ -146,3 +146,79 @@ def test_deleted_and_far_surfels_do_not_break_the_boxes():
         out[on] = run.coeffs(run.views())
     assert np.array_equal(bits(out[1][0]), bits(out[0][0])) and np.array_equal(out[1][1], out[0][1])
     assert np.isfinite(out[1][0]).all() and out[1][1].min() > 1000
+
+
+def _pcg_vectors(n, device):
+    import torch
+    vec = {nm: torch.full((max(1, n),), 123.0, dtype=torch.float32, device=device) for nm in ("r", "M", "delta", "g", "p")}
+    scal = torch.full((3,), 7.0, dtype=torch.float32, device=device)
+    v = abi.PCGVectors()
+    for nm, t in vec.items():
+        setattr(v, nm, t.data_ptr())
+    v.alpha_n, v.alpha_d, v.beta_n = scal.data_ptr(), scal.data_ptr() + 4, scal.data_ptr() + 8
+    return vec, scal, v
+
+
+@pytest.mark.parametrize("use_desc,intr", [(False, False), (True, False), (True, True)])
+def test_pcg_intrinsics_lifecycle_and_activation_with_and_without_culling(use_desc, intr):
+    """The other kernels that walk (surfel, keyframe) pairs in the library's work order: PCGInit / PCGStep1 (per-surfel and
+    per-keyframe entries, alpha_d), the alternating intrinsics step, the observation count of the surfel lifecycle and -- from
+    64 keyframes on -- the activation pass: identical bits with culling on and off, on a stack where most pairs are out of view."""
+    import torch
+    K = 72
+    dev = synthetic.TorchStack(K, "cuda:0", kind="trajectory", border_valid=True)
+    run = Runner(dev, use_desc)
+    L, h = run.L, run.ctx.handle
+    S = dev.surfels_size
+    kfs = run.views()
+    cells = dev.cfactor.shape[0] * dev.cfactor.shape[1]
+    per = 3 if use_desc else 1
+    n_pose, n_surf = 6 * (K - 1), per * S
+    depth_start = n_pose + n_surf if intr else abi.INVALID_INDEX
+    color_start = (depth_start + 5 + cells) if (intr and use_desc) else abi.INVALID_INDEX
+    total = n_pose + n_surf + ((5 + cells) if intr else 0) + (4 if (intr and use_desc) else 0)
+    layout = abi.PCGLayout(total, n_pose, depth_start, depth_start + 4 if intr else abi.INVALID_INDEX, color_start, 3,
+                           1, 1, int(intr), int(intr and use_desc), 1, int(use_desc))
+    start = dev.surfels.clone()
+    if use_desc:   # fitted descriptors (they start at 0)
+        run.geometry(kfs)
+        start = dev.surfels.clone()
+    out = {}
+    for on in (1, 0):
+        run.culling(on)
+        dev.surfels.copy_(start)
+        dev.active.fill_(0)
+        res = []
+        dp, sb, ab = dev.depth_params(), dev.buf(dev.surfels), dev.buf(dev.active)
+        # activation (K >= 64: per-surfel order + culling)
+        badslam_amd.check(L.bslam_update_surfel_activation(h, run.stream, C.byref(run.cam), C.byref(dp), K, kfs, S, C.byref(sb), C.byref(ab)))
+        res.append(dev.active[0, :S].cpu().numpy().copy())
+        # PCG init + init2 + step1
+        vec, scal, v = _pcg_vectors(total, "cuda:0")
+        badslam_amd.check(L.bslam_pcg_init(h, run.stream, C.byref(layout), C.byref(run.cam), C.byref(run.cam), C.byref(dp), K, kfs, S, C.byref(sb), C.byref(v)))
+        badslam_amd.check(L.bslam_pcg_init2(h, run.stream, C.byref(layout), 0.0, C.byref(v)))
+        badslam_amd.check(L.bslam_pcg_step1(h, run.stream, C.byref(layout), C.byref(run.cam), C.byref(run.cam), C.byref(dp), K, kfs, S, C.byref(sb), C.byref(v), 1))
+        torch.cuda.synchronize()
+        res += [bits(vec[nm].cpu().numpy()) for nm in ("r", "M", "g", "p")] + [bits(scal.cpu().numpy())]
+        # alternating intrinsics step
+        if intr:
+            out_c, out_d, a = abi.Camera4f(), abi.Camera4f(), C.c_float(0.0)
+            cf0 = dev.cfactor.clone()
+            badslam_amd.check(L.bslam_optimize_intrinsics(h, run.stream, 1, int(use_desc), K, kfs, C.byref(run.cam), C.byref(run.cam), C.byref(dp), S, C.byref(sb),
+                                                          C.byref(out_c), C.byref(out_d), C.byref(a)))
+            torch.cuda.synchronize()
+            res += [np.array([out_c.fx, out_c.fy, out_c.cx, out_c.cy, out_d.fx, out_d.fy, out_d.cx, out_d.cy, a.value], np.float32).view(np.uint32),
+                    bits(dev.cfactor.cpu().numpy())]
+            dev.cfactor.copy_(cf0)
+        # surfel lifecycle: observation counts, deletions, radii
+        cnt = C.c_uint32(S)
+        badslam_amd.check(L.bslam_delete_surfels_and_update_radii(h, run.stream, 2, C.byref(run.cam), C.byref(dp), K, kfs, C.byref(cnt), S, C.byref(sb)))
+        torch.cuda.synchronize()
+        res += [np.array([cnt.value]), bits(dev.surfels[:8].cpu().numpy())]
+        out[on] = res
+    dev.surfels.copy_(start)
+    assert len(out[1]) == len(out[0])
+    for i, (a_, b_) in enumerate(zip(out[1], out[0])):
+        assert np.array_equal(a_, b_), i
+    assert out[1][0].sum() > 0.9 * S                                    # activation did its job
+    assert np.isfinite(out[1][1].view(np.float32)).all()
