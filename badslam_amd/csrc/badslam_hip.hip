@@ -402,17 +402,26 @@ static unsigned long long* cull_stats_ptr(bslam_context* ctx) {
 // all its iterations), or nullptr to prepare them here.
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
-                                  int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr, int* kfs_per_block_out = nullptr) {
+                                  int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr, int* kfs_per_block_out = nullptr,
+                                  bool want_cost = false) {
   SurfelWork local;
   int rc = BSLAM_OK;
   if (!work) {
     if ((rc = prepare_surfels(ctx, stream, surfels, surfels_size, pose_surfels_per_thread(use_desc != 0, surfels_size), kf_count, &local, use_desc != 0))) return rc;
     work = &local;
   }
-  const Schedule sc = work->sc;
+  Schedule sc = work->sc;
+  // A block of this kernel walks a chunk of <= 32 keyframes of one work slot; on short keyframe lists the chunks are so short
+  // (6 keyframes at K = 50) that the culling test at the head of every block costs more than it saves on any stack we have
+  // (K = 50 dense, 12 % of the blocks culled: 96 -> 102 us per launch).  The geometry / PCG / intrinsics kernels walk the whole
+  // list per block and keep it.
+#ifndef BSLAM_POSE_CULL_MIN_KEYFRAMES
+#define BSLAM_POSE_CULL_MIN_KEYFRAMES 64
+#endif
+  if (kf_count < BSLAM_POSE_CULL_MIN_KEYFRAMES) sc.bounds = nullptr;
   const int tiles = (int)sc.slots;
   *tiles_out = tiles;
-  const int rows_per_kf = tiles * (kPoseThreads / 64);   // one partial row per (slot, wave)
+  const int rows_per_kf = tiles * kPoseRowsPerSlot;   // one partial row per (slot, wave), or per slot
   const size_t partial_floats = (size_t)rows_per_kf * kf_count * kRow;
   rc = ctx->partials.reserve((partial_floats + (size_t)kf_count * kReduceParts * kRow) * sizeof(float));
   if (rc) return rc;
@@ -431,10 +440,17 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   static const unsigned debug_lds = getenv("BSLAM_DEBUG_POSE_LDS") ? (unsigned)atoi(getenv("BSLAM_DEBUG_POSE_LDS")) : 0u;
   {
   ProfScope prof(ctx, stream);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
-  else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeoLarge>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false, kPoseRGeo>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true, kPoseRDesc>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);
+  const bool cost = want_cost;
+#define BSLAM_LAUNCH_POSE(DEPTH, DESC, R)                                                                                                        \
+  do {                                                                                                                                           \
+    if (cost) hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, true>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);  \
+    else hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, false>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis); \
+  } while (0)
+  if (use_depth && use_desc) BSLAM_LAUNCH_POSE(true, true, kPoseRDesc);
+  else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) BSLAM_LAUNCH_POSE(true, false, kPoseRGeoLarge);
+  else if (use_depth) BSLAM_LAUNCH_POSE(true, false, kPoseRGeo);
+  else BSLAM_LAUNCH_POSE(false, true, kPoseRDesc);
+#undef BSLAM_LAUNCH_POSE
   }
   BSLAM_HIP_TRY(hipGetLastError());
   if (!reduce_rows) return BSLAM_OK;   // the caller's pose_reduce_solve_kernel sums the rows itself
@@ -824,7 +840,7 @@ int bslam_accumulate_pose_estimation_coeffs(
   const CamConsts c = make_cam_consts(ctx, color_camera, depth_camera, depth_params);
   if ((rc = upload_kf_table(ctx, stream, table, c))) return rc;
   int tiles = 0;
-  if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, 1, surfels_size, surfels, nullptr, &tiles))) return rc;
+  if ((rc = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, 1, surfels_size, surfels, nullptr, &tiles, true, nullptr, nullptr, debug != 0))) return rc;
   if ((rc = ctx->staging2.reserve(kRow * sizeof(float)))) return rc;
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, ctx->coeffs.ptr, kRow * sizeof(float), hipMemcpyDeviceToHost, stream));
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));   // results valid on return, BS/kernel_opt_pose.cc:96
@@ -936,7 +952,7 @@ int bslam_estimate_frame_poses_batched(
       {
         ProfScope prof(ctx, stream, BSLAM_PROF_POSE_REDUCE);
         hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), (unsigned)visit_map_bytes(tiles), stream, (const float*)ctx->partials.ptr,
-                           tiles * (kPoseThreads / 64), keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3),
+                           tiles * kPoseRowsPerSlot, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3),
                            (const uint32_t*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx));
       }
       BSLAM_HIP_TRY(hipGetLastError());

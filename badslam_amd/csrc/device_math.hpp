@@ -916,6 +916,48 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   return dpp_add_xor1(v[0], v[0]);
 }
 
+// The same sums through LDS: the wave writes kCols columns at a time into a [kCols][64] tile (ds_write_b32 per column,
+// conflict-free), every lane reads back kCols neighbouring lanes' values of ONE column (ds_read_b128s: with L = 64 / kCols lanes
+// per column, lane (g, i) = (lane / L, lane % L) reads entries kCols i .. kCols i + kCols - 1 of column g), adds them and finishes
+// with log2(L) DPP adds among the L lanes of its column.  For kCols = 4 that is about 15 instructions per 4 columns, of which 8
+// VALU, instead of ~20 (16 VALU) for the butterfly's selects, ds_bpermutes and adds; the wave's own LDS operations execute in
+// order, so no barrier is needed and the tile is private to the wave.  Columns [0, kLive) are summed; afterwards lane (g, i)
+// with i < 32 / kCols holds the wave total of column kCols i + g (0 for a column >= kLive).  Fixed order: deterministic.
+template <int kLive, int kCols>
+__device__ __forceinline__ float wave_column_sums_lds(const float (&v)[32], float* __restrict__ tile) {
+  static_assert(kLive >= 1 && kLive <= 32, "at most 32 columns");
+  static_assert(kCols == 4 || kCols == 8 || kCols == 16, "4, 8 or 16 columns per round");
+  constexpr uint32_t L = 64 / kCols;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane / L, i = lane % L;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < (kLive + kCols - 1) / kCols; ++r) {
+#pragma unroll
+    for (int q = 0; q < kCols; ++q)
+      if (kCols * r + q < kLive) tile[q * 64 + lane] = v[kCols * r + q];
+    __builtin_amdgcn_wave_barrier();
+    float part[kCols / 4];
+#pragma unroll
+    for (int q = 0; q < kCols / 4; ++q) {
+      const v4f x = *reinterpret_cast<const v4f*>(tile + g * 64 + i * kCols + 4 * q);
+      part[q] = (x.x + x.y) + (x.z + x.w);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float t = part[0];
+    if constexpr (kCols == 8) t = part[0] + part[1];
+    if constexpr (kCols == 16) t = (part[0] + part[1]) + (part[2] + part[3]);
+    t = dpp_add_xor1(t, t);
+    t = dpp_add_xor2(t, t);
+    if constexpr (L >= 8) t = dpp_add_half_mirror(t, t);
+    if constexpr (L >= 16) t = dpp_add_ror8(t, t);
+    const bool take = (i == (uint32_t)r) && (kCols * r + kCols - 1 < kLive || (uint32_t)(kCols * r) + g < (uint32_t)kLive);
+    mine = take ? t : mine;
+  }
+  return mine;
+}
+
 // Generic form for N = 8 or 16 values: N - 1 exchanges down to one value per lane, then log2(64 / N)
 // butterfly steps.  Afterwards every lane holds the wave total of column (lane / (64 / N)) % N.
 template <int N>

@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256) void activation_kernel(CamConsts c, const KfDe
   const f3 gp = mk3(s.x[j], s.y[j], s.z[j]);
   const f3 gn = unpack_normal(s.normal[j]);
   bool searching = valid;   // until the surfel's first associated ACTIVE keyframe
-  BSLAM_FOR_VISITED_KEYFRAMES_IF(k, 0, kf_count, 1, keyframe_active(kfs, k0_, kf_count)) {
-    if (!__any(searching)) break;   // uniform; the outer batch loop ends below
-    if (searching) {
+  for (int k0 = 0; k0 < kf_count && __any(searching); k0 += 64) {   // uniform: 64 keyframes are decided at a time, one per lane
+    for (unsigned long long todo = keyframes_to_visit(c, kfs, k0, kf_count, sc, slot, 1, keyframe_active(kfs, k0, kf_count)); todo != 0 && __any(searching); todo &= todo - 1) {
+      if (!searching) continue;
+      const int k = k0 + __builtin_ctzll(todo);
       if (kCount) visited += 1;
       Proj p;
       if (project_and_associate(c, kfs[k], gp, gn, &p)) { flag = BSLAM_SURFEL_ACTIVE_FLAG; activated = 1; searching = false; }

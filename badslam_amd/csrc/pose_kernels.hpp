@@ -11,12 +11,15 @@
 //     walks the keyframes of its chunk, so surfel bytes are read once per chunk instead of once
 //     per keyframe; the surfels come in the library's per-surfel Morton order (sorted copy of the
 //     rows, badslam_hip.hip: prepare_surfels), so a wave's 64 surfels are a compact blob;
-//   * the 21 + 6 (+ cost, count) coefficients are accumulated per thread over its kR surfels
-//     (fused multiply-adds: these sums are compared at 1e-4, only the association predicates
-//     need bit-exact arithmetic), reduced across the wave with a transposing butterfly
-//     (32 exchanges for 32 values) and written as one coalesced 32-float row per (wave, keyframe):
-//     no LDS, no barrier in the keyframe loop; a second kernel sums the rows in a fixed order:
-//     deterministic, no float atomics;
+//   * the 21 + 6 (+ cost) coefficients are accumulated per thread over its kR surfels (fused
+//     multiply-adds: these sums are compared at 1e-4, only the association predicates need
+//     bit-exact arithmetic), reduced across the wave through a wave-private LDS tile (8 columns
+//     per round: ds_write / ds_read_b128 / three DPP adds, no barrier) and the four waves' rows
+//     meet in an LDS stash, so that ONE 32-float row per (work slot, keyframe) leaves the block,
+//     with one barrier per four visited keyframes; a second kernel sums the rows in a fixed
+//     order: deterministic, no float atomics;
+//   * a block decides up front which keyframes of its chunk its surfels can be seen from at all
+//     (block-level frustum culling, device_math.hpp) and visits only those;
 //   * the 6x6 solve, SE3 update and convergence test run on the device (one thread per
 //     keyframe), all keyframes advance in lock-step.
 #pragma once
@@ -93,7 +96,20 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 #define BSLAM_POSE_WAVES_DESC 5
 #endif
 #define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : (kPoseR > 4 ? 5 : BSLAM_POSE_WAVES_GEO))))
-template <bool kDepth, bool kDesc, int kPoseR>
+// Wave reduction of a row through LDS, kRedCols columns per round (wave_column_sums_lds; tile: kRedCols x 64 floats per wave).
+// Measured against the transposing butterfly (wave_transpose_sum32, still used by the image-pair kernels) on one box: photometric
+// K = 300 pose kernel 14.90 -> 14.37 ms with 8 columns per round (4: no gain; 16: the tile costs the photometric kernel a
+// block per CU), geometry-only K = 50 / 200: 94.6 -> 90.8 us / 1206 -> 1160 us.
+constexpr int kRedCols = 8;
+// One partial row per (work slot, keyframe): the four waves' rows meet in an LDS stash, one barrier per kPoseStashGroup visited
+// keyframes (two stashes alternate, so a wave that runs ahead never overwrites rows that are still being added; it cannot get
+// two groups ahead: the barrier).  A quarter of the row traffic of one row per wave: the row sums of a batched Gauss-Newton
+// iteration at K = 300 go from 428 to about 110 us.
+constexpr int kPoseRowsPerSlot = 1;
+constexpr int kPoseStashGroup = 4;
+// kCost: the robust cost (column kRowCost) is wanted -- only the per-keyframe debug entry point returns it; the batched
+// Gauss-Newton loop never does, and leaves the tukey / huber residual evaluations out.
+template <bool kDepth, bool kDesc, int kPoseR, bool kCost>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
     SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, uint32_t* __restrict__ vis) {
@@ -124,11 +140,26 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
   f3 gp[kPoseR], gn[kPoseR];
   bool valid[kPoseR];
-  // Photometric variant: the 14 per-surfel constants (position, normal, the two tangent sample points of the descriptor
-  // residual, the descriptor) live in LDS -- [component][thread]: conflict-free, private to the thread, no barrier -- instead
-  // of 28 VGPRs, and are read back where a pair needs them: 123 -> 95 VGPRs, one more wave per SIMD (518 -> 495 us at K = 50).
-  constexpr int kState = 14;
+  // Photometric variant: 12 per-surfel constants (position, normal, the two tangent sample points of the descriptor
+  // residual) live in LDS -- [component][thread]: conflict-free, private to the thread, no barrier -- instead of 24 VGPRs, and
+  // are read back where a pair needs them (round 2: 123 -> 95 VGPRs, 518 -> 495 us at K = 50).
+  constexpr int kState = 12;
   __shared__ float state[kDesc ? kState * kPoseR * kPoseThreads : 1];
+  float desc1[kDesc ? kPoseR : 1], desc2[kDesc ? kPoseR : 1];   // in registers: 24 + 8 + 4 KB of LDS per block leave four blocks per CU
+  __shared__ float row_stash[2][kPoseStashGroup][kPoseThreads / 64][kRow];
+  __shared__ int stash_kf[2][kPoseStashGroup];
+  int stashed = 0, stash_buf = 0;   // uniform
+  // adds up the four waves' rows of the `n` stashed keyframes -- ((w0 + w1) + w2) + w3 -- and stores one row per keyframe
+  auto flush_rows = [&](int n) {
+    __syncthreads();
+    const int j = threadIdx.x / kRow, col = threadIdx.x % kRow;
+    if (j < n) {
+      const float (*w)[kRow] = row_stash[stash_buf][j];
+      partials[((size_t)stash_kf[stash_buf][j] * rows_per_kf + (size_t)tile) * kRow + col] = ((w[0][col] + w[1][col]) + w[2][col]) + w[3][col];
+    }
+  };
+  static_assert(kPoseStashGroup * kRow <= kPoseThreads && kPoseThreads / 64 == 4, "one thread per stashed column; four waves");
+  __shared__ __attribute__((aligned(16))) float red_tile[kPoseThreads / 64][kRedCols * 64];   // wave-private tiles of the row reduction
   auto st = [&](int r, int comp) -> float& { return state[(r * kState + comp) * kPoseThreads + threadIdx.x]; };
 #pragma unroll
   for (int r = 0; r < kPoseR; ++r) {
@@ -144,7 +175,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
       st(r, 3) = gn[r].x; st(r, 4) = gn[r].y; st(r, 5) = gn[r].z;
       st(r, 6) = tp1.x; st(r, 7) = tp1.y; st(r, 8) = tp1.z;
       st(r, 9) = tp2.x; st(r, 10) = tp2.y; st(r, 11) = tp2.z;
-      st(r, 12) = s.d1[j]; st(r, 13) = s.d2[j];
+      desc1[r] = s.d1[j]; desc2[r] = s.d2[j];
     }
   }
 
@@ -155,66 +186,74 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     float acc[kRow];
 #pragma unroll
     for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
+    // residual count of the wave: formed from ballots at the points where the lanes have reconverged (s_bcnt1 on the mask: no
+    // VALU, and one column less in the reduction below); uniform
     uint32_t count = 0;
 
 #pragma unroll
     for (int r = 0; r < kPoseR; ++r) {
-      Proj p;
-      DescSamples ds;
-      bool has_desc = false;
-      if (!valid[r]) continue;
-      if constexpr (!kDesc) {
-        if (!project_and_associate(c, kf, gp[r], gn[r], &p)) continue;
-      } else {
-        // The descriptor samples depend on the surfel and the pose only, not on the pixel record: their three quad gathers
-        // are issued together with the record gather, BEFORE the association test (99.6 % of the in-bounds pairs pass it),
-        // so a pair waits for one L2 round trip instead of two and the depth residual is evaluated while the quads are in
-        // flight (551 -> 517 us at K = 50).  Issued unconditionally -- the quad table's clamp addressing makes every address
-        // valid -- so that no control-flow join sits in front of the record's wait (s_waitcnt vmcnt(3), not vmcnt(0)).
-        if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) continue;
-        const PixelRecord rec = load_record(c, kf, p);
-        f2 color_pxy, t1, t2;
-        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
-        project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
-        ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
-        asm volatile("" ::: "memory");   // keeps the compiler from sinking the gathers below the branches that follow
-        if (!associate_with_record(c, kf, mk3(st(r, 3), st(r, 4), st(r, 5)), rec, &p)) continue;
-      }
-      float J[6];
-      float raw;
-      if (kDepth) {                                           // BS/kernel_opt_pose.cu:283-317
-        depth_residual_and_jacobian(c, p, &raw, J);
-        accumulate_h_b(raw, depth_weight(raw), J, acc);
-        acc[kRowCost] += weighted_depth_residual(raw);
-        count += 1;
-      }
-      if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
-        if (has_desc) {
-          float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_samples_finish(kf, c, ds, st(r, 12), st(r, 13), &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
-          gx1 *= c.cfx; gx2 *= c.cfx;
-          gy1 *= c.cfy; gy2 *= c.cfy;
-          descriptor_pose_jacobian(gx1, gy1, p.local, J);
-          accumulate_h_b(r1, desc_weight(r1), J, acc);
-          descriptor_pose_jacobian(gx2, gy2, p.local, J);
-          accumulate_h_b(rr2, desc_weight(rr2), J, acc);
-          acc[kRowCost] += weighted_desc_residual(r1);        // quirk Q1: only the first residual is counted
-          count += 1;
+      bool got_depth = false, got_desc = false;
+      do {
+        Proj p;
+        DescSamples ds;
+        bool has_desc = false;
+        if (!valid[r]) break;
+        if constexpr (!kDesc) {
+          if (!project_and_associate(c, kf, gp[r], gn[r], &p)) break;
+        } else {
+          // The descriptor samples depend on the surfel and the pose only, not on the pixel record: their three quad gathers
+          // are issued together with the record gather, BEFORE the association test (99.6 % of the in-bounds pairs pass it),
+          // so a pair waits for one L2 round trip instead of two and the depth residual is evaluated while the quads are in
+          // flight (551 -> 517 us at K = 50).  Issued unconditionally -- the quad table's clamp addressing makes every address
+          // valid -- so that no control-flow join sits in front of the record's wait (s_waitcnt vmcnt(3), not vmcnt(0)).
+          if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) break;
+          const PixelRecord rec = load_record(c, kf, p);
+          f2 color_pxy, t1, t2;
+          has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+          project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
+          ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+          asm volatile("" ::: "memory");   // keeps the compiler from sinking the gathers below the branches that follow
+          if (!associate_with_record(c, kf, mk3(st(r, 3), st(r, 4), st(r, 5)), rec, &p)) break;
         }
-      }
+        float J[6];
+        float raw;
+        if (kDepth) {                                           // BS/kernel_opt_pose.cu:283-317
+          depth_residual_and_jacobian(c, p, &raw, J);
+          accumulate_h_b(raw, depth_weight(raw), J, acc);
+          if constexpr (kCost) acc[kRowCost] += weighted_depth_residual(raw);
+          got_depth = true;
+        }
+        if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
+          if (has_desc) {
+            float r1, rr2, gx1, gy1, gx2, gy2;
+            descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+            gx1 *= c.cfx; gx2 *= c.cfx;
+            gy1 *= c.cfy; gy2 *= c.cfy;
+            descriptor_pose_jacobian(gx1, gy1, p.local, J);
+            accumulate_h_b(r1, desc_weight(r1), J, acc);
+            descriptor_pose_jacobian(gx2, gy2, p.local, J);
+            accumulate_h_b(rr2, desc_weight(rr2), J, acc);
+            if constexpr (kCost) acc[kRowCost] += weighted_desc_residual(r1);        // quirk Q1: only the first residual is counted
+            got_desc = true;
+          }
+        }
+      } while (false);
+      count += (uint32_t)__builtin_popcountll(__ballot(got_depth)) + (uint32_t)__builtin_popcountll(__ballot(got_desc));
     }
 
-    // wave reduction (skipped when the whole wave saw nothing for this keyframe); the residual
-    // count (<= 64 * kPoseR per wave) travels as an exactly representable float in column kRowCount
-    const bool any = __any(count != 0);
+    // wave reduction (skipped when the whole wave saw nothing for this keyframe)
+    const bool any = count != 0;   // uniform
     float total = 0.f;
-    if (any) {
-      acc[kRowCount] = (float)count;
-      total = wave_transpose_sum32(acc);
-    }
-    if ((lane & 1) == 0)
-      partials[((size_t)k * rows_per_kf + (size_t)tile * (kPoseThreads / 64) + wave) * kRow + (lane >> 1)] = total;
+    constexpr int kLive = kCost ? kRowCost + 1 : kRowCost;   // 21 H, 6 b (, cost); the count column is filled in below
+    if (any) total = wave_column_sums_lds<kLive, kRedCols>(acc, red_tile[wave]);
+    constexpr int kRedLanes = 64 / kRedCols;   // lanes per column: lane (g, i) = (lane / kRedLanes, lane % kRedLanes) holds column kRedCols i + g
+    const int my_col = kRedCols * (lane % kRedLanes) + lane / kRedLanes;
+    if (my_col == kRowCount) total = (float)count;   // <= 64 * kPoseR: exact
+    if ((lane % kRedLanes) < kRow / kRedCols) row_stash[stash_buf][stashed][wave][my_col] = total;
+    if (threadIdx.x == 0) stash_kf[stash_buf][stashed] = k;
+    if (++stashed == kPoseStashGroup) { flush_rows(stashed); stashed = 0; stash_buf ^= 1; }
   }
+  if (stashed) flush_rows(stashed);
 }
 
 // Sums the partial rows [k][row][32] of one keyframe in a fixed order, in two stages so that the
@@ -273,14 +312,18 @@ __global__ __launch_bounds__(64) void pose_reduce_final_kernel(const float* __re
 // same bits with and without culling.  Eight independent partial sums keep eight loads in flight; a row that is skipped
 // loads a zero from a fixed address instead of branching around the load.
 __device__ const float kZeroFloat = 0.f;
-constexpr int kRowsPerSlot = kPoseThreads / 64;
-__host__ __device__ __forceinline__ size_t visit_map_bytes(int slots) { return (size_t)((slots + 63) / 64) * sizeof(unsigned long long); }
+constexpr int kRowsPerSlot = kPoseRowsPerSlot;
+constexpr int kSlotsPerPass = 256 / kRowsPerSlot;        // a pass of the 32 x 8 partial sums covers 256 rows
+constexpr int kWordsPerPass = (kSlotsPerPass + 63) / 64;   // 1 (four rows per slot) or 4 (one)
+__host__ __device__ __forceinline__ size_t visit_map_bytes(int slots) {
+  return (size_t)(((slots + kSlotsPerPass - 1) / kSlotsPerPass) * kWordsPerPass) * sizeof(unsigned long long);
+}
 // Returns the number of visiting slots (valid in every thread after the trailing barrier).
 __device__ __forceinline__ uint32_t build_visit_map(const uint32_t* __restrict__ vis, uint32_t bit, int slots, unsigned long long* __restrict__ vmap) {
   __shared__ uint32_t visiting;
   if (threadIdx.x == 0) visiting = 0;
   __syncthreads();
-  const int padded = (slots + 63) & ~63;
+  const int padded = (int)(visit_map_bytes(slots) / sizeof(unsigned long long)) * 64;
   uint32_t mine = 0;
   for (int s0 = 0; s0 < padded; s0 += (int)blockDim.x) {
     const int sl = s0 + (int)threadIdx.x;
@@ -295,21 +338,24 @@ __device__ __forceinline__ uint32_t build_visit_map(const uint32_t* __restrict__
 __device__ __forceinline__ float column_share_of_rows(const float* __restrict__ base, int sub, int rows, const unsigned long long* __restrict__ vmap) {
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* zero = &kZeroFloat;
-  for (int g = 0; g * (64 * kRowsPerSlot) < rows; ++g) {
-    const unsigned long long w = vmap[g];   // the 64 slots whose rows this group holds: uniform
-    if (w == 0) continue;
+  for (int pass = 0; pass * 256 < rows; ++pass) {
+    const unsigned long long* w = vmap + pass * kWordsPerPass;   // the slots whose rows this pass holds: uniform
+    unsigned long long any = w[0];
+#pragma unroll
+    for (int q = 1; q < kWordsPerPass; ++q) any |= w[q];
+    if (any == 0) continue;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int in_group = sub + 32 * u;
-      const int r = g * (64 * kRowsPerSlot) + in_group;
-      const bool take = r < rows && ((w >> (in_group / kRowsPerSlot)) & 1ull);
+      const int in_pass = sub + 32 * u;
+      const int r = pass * 256 + in_pass;
+      const int sl = in_pass / kRowsPerSlot;
+      const bool take = r < rows && ((w[sl >> 6] >> (sl & 63)) & 1ull);
       const float* p = take ? base + (size_t)r * kRow : zero;
       v[u] += *p;
     }
   }
   return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
-static_assert(64 * kRowsPerSlot == 8 * 32, "a group of 64 slots must be the 256 rows one pass of the 32 x 8 partial sums covers");
 
 // Both stages in one launch for the batched loop with an all-reduce hook: block k (1024 threads) sums keyframe k's
 // rows coalesced in the same fixed order as pose_reduce_solve_kernel and writes the coefficient row that goes through

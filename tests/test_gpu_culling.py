@@ -80,8 +80,9 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("kind,K,use_desc", [("dense", 8, True), ("survey", 12, False), ("survey", 12, True),
-                                             ("trajectory", 40, False), ("trajectory", 40, True)])
+# the pose kernel culls from 64 keyframes on (shorter lists: its blocks are too short to pay for the test), the geometry passes always
+@pytest.mark.parametrize("kind,K,use_desc", [("dense", 8, True), ("dense", 64, False), ("survey", 12, False), ("survey", 66, True),
+                                             ("trajectory", 40, False), ("trajectory", 72, False), ("trajectory", 72, True)])
 def test_outputs_are_bit_identical_with_and_without_culling(kind, K, use_desc):
     import torch
     dev = synthetic.TorchStack(K, "cuda:0", kind=kind, border_valid=True)
@@ -124,9 +125,11 @@ def test_outputs_are_bit_identical_with_and_without_culling(kind, K, use_desc):
     frac = out[1][2] / out[1][1]
     counts = out[1][0][1]
     assert counts.min() > 1000, counts.min()                 # the sums are not trivially empty
-    if kind == "trajectory":
+    if K < 64:
+        assert frac == 0.0                                   # short keyframe lists: the pose kernel visits everything
+    elif kind == "trajectory":
         assert frac > 0.6, frac                              # most of the room is out of view of a keyframe
-    if kind == "survey":
+    elif kind == "survey":
         assert frac > 0.2, frac
 
 
