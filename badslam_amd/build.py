@@ -11,7 +11,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off + correctly rounded fp32 divide/sqrt: the association predicates must round
 # exactly like the CPU oracle's (bit-exact integer outputs); see DESIGN.md "Numerics".
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 # -fno-slp-vectorize: v_pk_{mul,add,fma}_f32 issue at half rate on gfx950 (measured, tools/microbench_valu.hip), so
 # SLP-packed fp32 gains nothing and costs v_mov packing + ~40 % more VGPRs; pose kernel -19 %, see DESIGN.md.
 

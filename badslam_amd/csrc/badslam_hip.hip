@@ -56,6 +56,7 @@ static CamConsts make_cam_consts(const bslam_context* ctx, const bslam_camera4f*
   c.cfactor_pitch = (uint32_t)dp->cfactor_buffer.pitch;
   c.cfactor_width = dp->cfactor_buffer.width;
   c.tex_mode = ctx->tex_mode;
+  c.d2c_identity = color && c.d2c_fx == 1.0f && c.d2c_fy == 1.0f && c.d2c_cx == 0.0f && c.d2c_cy == 0.0f && c.color_width == c.width && c.color_height == c.height;
   return c;
 }
 

@@ -67,6 +67,7 @@ struct CamConsts {
   uint32_t cfactor_pitch; // bytes
   int cfactor_width;
   int tex_mode;
+  int d2c_identity;       // d2c_fx = d2c_fy = 1, d2c_cx = d2c_cy = 0 and equal image sizes (set by make_cam_consts)
 };
 
 #ifndef BSLAM_PROJECT_SINGLE_BRANCH
@@ -319,11 +320,13 @@ __device__ __forceinline__ TexFootprint tex_footprint(const CamConsts& c, float 
     f.a = floorf(f.a * 256.0f + 0.5f) * (1.0f / 256.0f);
     f.b = floorf(f.b * 256.0f + 0.5f) * (1.0f / 256.0f);
   }
-  f.interior = xb >= 0.f && yb >= 0.f && xb < (float)(c.color_width - 1) && yb < (float)(c.color_height - 1);
   // clamp = v_med3_f32 (same selection as fminf(fmaxf(.)) for the finite arguments that reach this point, without the
   // two NaN-quieting moves fminf / fmaxf cost each)
   f.i = (int)__builtin_amdgcn_fmed3f(fx, -1.0f, (float)(c.color_width - 1));
   f.j = (int)__builtin_amdgcn_fmed3f(fy, -1.0f, (float)(c.color_height - 1));
+  // 0 <= xb < w - 1  <=>  0 <= floor(xb) <= w - 2 (w - 1 is an integer)  <=>  the clamped base texel lies in [0, w - 2]: two
+  // unsigned compares instead of four float compares
+  f.interior = ((uint32_t)f.i < (uint32_t)(c.color_width - 1)) & ((uint32_t)f.j < (uint32_t)(c.color_height - 1));
   return f;
 }
 __device__ __forceinline__ float tex_filter(const LumaQuad& t, float a, float b) {
@@ -477,6 +480,13 @@ __device__ __forceinline__ bool depth_to_color_pxy(const CamConsts& c, f2 pxy, f
   out->x = c.d2c_fx * pxy.x + c.d2c_cx;
   out->y = c.d2c_fy * pxy.y + c.d2c_cy;
   return out->x >= 0 && out->y >= 0 && f2i(out->x) < c.color_width && f2i(out->y) < c.color_height;
+}
+// The same for a pixel position that has already passed the depth image's bounds test (project_to_pixel).  When both cameras
+// share intrinsics and size (every RGB-D dataset registered to the depth frame: 1 * x + 0 is x, bit for bit, for x >= 0) the
+// map is the identity and the test is already known to pass: a uniform branch instead of ten VALU instructions per pair.
+__device__ __forceinline__ bool depth_to_color_pxy_in_bounds(const CamConsts& c, f2 pxy, f2* out) {
+  if (c.d2c_identity) { *out = pxy; return true; }
+  return depth_to_color_pxy(c, pxy, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -922,10 +932,10 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
 // with log2(L) DPP adds among the L lanes of its column.  For kCols = 4 that is about 15 instructions per 4 columns, of which 8
 // VALU, instead of ~20 (16 VALU) for the butterfly's selects, ds_bpermutes and adds; the wave's own LDS operations execute in
 // order, so no barrier is needed and the tile is private to the wave.  Columns [0, kLive) are summed; afterwards lane (g, i)
-// with i < 32 / kCols holds the wave total of column kCols i + g (0 for a column >= kLive).  Fixed order: deterministic.
-template <int kLive, int kCols>
-__device__ __forceinline__ float wave_column_sums_lds(const float (&v)[32], float* __restrict__ tile) {
-  static_assert(kLive >= 1 && kLive <= 32, "at most 32 columns");
+// with i < ceil(kLive / kCols) holds the wave total of column kCols i + g (0 for a column >= kLive).  Fixed order: deterministic.
+template <int kLive, int kCols, int N>
+__device__ __forceinline__ float wave_column_sums_lds(const float (&v)[N], float* __restrict__ tile) {
+  static_assert(kLive >= 1 && kLive <= N && N <= 32, "at most 32 columns");
   static_assert(kCols == 4 || kCols == 8 || kCols == 16, "4, 8 or 16 columns per round");
   constexpr uint32_t L = 64 / kCols;
   const uint32_t lane = threadIdx.x & 63u;

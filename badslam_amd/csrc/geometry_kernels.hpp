@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         if (!on[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy, t1, t2;
-        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
         ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
         asm volatile("" ::: "memory");

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
         f2 color_pxy, t1, t2;
-        has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+        has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
         ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
         asm volatile("" ::: "memory");

@@ -95,7 +95,7 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 #ifndef BSLAM_POSE_WAVES_DESC
 #define BSLAM_POSE_WAVES_DESC 5
 #endif
-#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : (kPoseR > 4 ? 5 : BSLAM_POSE_WAVES_GEO))))
+#define BSLAM_POSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_POSE_WAVES_DESC : ((kPoseR > 4 || kCost) ? 5 : BSLAM_POSE_WAVES_GEO))))
 // Wave reduction of a row through LDS, kRedCols columns per round (wave_column_sums_lds; tile: kRedCols x 64 floats per wave).
 // Measured against the transposing butterfly (wave_transpose_sum32, still used by the image-pair kernels) on one box: photometric
 // K = 300 pose kernel 14.90 -> 14.37 ms with 8 columns per round (4: no gain; 16: the tile costs the photometric kernel a
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
           if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) break;
           const PixelRecord rec = load_record(c, kf, p);
           f2 color_pxy, t1, t2;
-          has_desc = depth_to_color_pxy(c, p.pxy, &color_pxy);
+          has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
           project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
           ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
           asm volatile("" ::: "memory");   // keeps the compiler from sinking the gathers below the branches that follow
