@@ -70,12 +70,6 @@ struct CamConsts {
   int d2c_identity;       // d2c_fx = d2c_fy = 1, d2c_cx = d2c_cy = 0 and equal image sizes (set by make_cam_consts)
 };
 
-#ifndef BSLAM_PROJECT_SINGLE_BRANCH
-#define BSLAM_PROJECT_SINGLE_BRANCH 1
-#endif
-#ifndef BSLAM_ASSOC_SINGLE_BRANCH
-#define BSLAM_ASSOC_SINGLE_BRANCH 1
-#endif
 struct __attribute__((aligned(16))) PixelRecord { float depth, nx, ny, nz; };
 
 // Device view of one keyframe (pointers + pose), kept in a device array and read with scalar loads.
@@ -106,11 +100,7 @@ __device__ __forceinline__ f3 unproject(const CamConsts& c, int x, int y, float 
 // fmas, a multiply, v_div_fmas, v_div_fixup) with the parts that only serve numerators != 1, denormal scaling and special
 // operands removed -- the same v_rcp seed and the same fma chain, so the same bits as 1.0f / x there, in 7 instead of 11
 // instructions.  (tests/test_gpu_parity.py::test_midrange_reciprocal_is_correctly_rounded sweeps it against 1.0f / x.)
-#ifndef BSLAM_RCP_MIDRANGE
-#define BSLAM_RCP_MIDRANGE 1
-#endif
 __device__ __forceinline__ float rcp_rn_midrange(float x) {
-#if BSLAM_RCP_MIDRANGE
   const float r0 = __builtin_amdgcn_rcpf(x);
   const float e0 = __builtin_fmaf(-x, r0, 1.0f);
   const float r1 = __builtin_fmaf(e0, r0, r0);
@@ -118,9 +108,6 @@ __device__ __forceinline__ float rcp_rn_midrange(float x) {
   const float r2 = __builtin_fmaf(e1, r1, r1);
   const float e2 = __builtin_fmaf(-x, r2, 1.0f);
   return __builtin_fmaf(e2, r1, r2);
-#else
-  return 1.0f / x;
-#endif
 }
 
 __device__ __forceinline__ f2 project(float fx, float fy, float cx, float cy, f3 p) {                       // BS/surfel_projection.cuh:52
@@ -202,30 +189,16 @@ __device__ __forceinline__ f3 unpack_normal(uint32_t value) {
 // -use_fast_math (BS/CMakeLists.txt:67), i.e. with approximate division and square root throughout; here
 //  - everything that feeds an INTEGER output (project_and_associate, normal quantisation) uses the correctly
 //    rounded forms, so associations / counts / packed normals are bit-identical to the oracle's;
-//  - level 1 (default): robust weights, inverse stddev and Jacobian factors use the 1-ulp v_rcp_f32
-//    (smooth functions: a 1-ulp input change is a ~1e-7 relative output change);
-//  - level 2 (opt-in): the tangent sample points too.  With the 1.8 fixed-point texture weights a 1-ulp
-//    move of a sample point can flip a quantised weight (a ~1e-4..1e-3 jump of one descriptor residual), which
-//    is why it is not the default;  level 0 = everything correctly rounded.
-#ifndef BSLAM_FAST_RESIDUAL_MATH
-#define BSLAM_FAST_RESIDUAL_MATH 1
-#endif
-#if BSLAM_FAST_RESIDUAL_MATH >= 1
+//  - robust weights, inverse stddev and Jacobian factors (rdiv, rrcp) use the 1-ulp v_rcp_f32: smooth functions, a
+//    1-ulp input change is a ~1e-7 relative output change;
+//  - the tangent sample points (sdiv, srcp, ssqrt) stay correctly rounded: with the 1.8 fixed-point texture weights a
+//    1-ulp move of a sample point can flip a quantised weight (a ~1e-4..1e-3 jump of one descriptor residual;
+//    measured in round 2 with the raw v_rcp_f32 there).
 __device__ __forceinline__ float rdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float rrcp(float b) { return __builtin_amdgcn_rcpf(b); }
-#else
-__device__ __forceinline__ float rdiv(float a, float b) { return a / b; }
-__device__ __forceinline__ float rrcp(float b) { return 1.f / b; }
-#endif
-#if BSLAM_FAST_RESIDUAL_MATH >= 2
-__device__ __forceinline__ float sdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float srcp(float b) { return __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-#else
 __device__ __forceinline__ float sdiv(float a, float b) { return a / b; }
 __device__ __forceinline__ float srcp(float b) { return rcp_rn_midrange(b); }
 __device__ __forceinline__ float ssqrt(float x) { return sqrtf(x); }
-#endif
 
 // BS/robust_weighting.cuh:39-86
 __device__ __forceinline__ float tukey_weight(float r, float k) {
@@ -549,20 +522,14 @@ __global__ __launch_bounds__(256) void build_quads_kernel(CamConsts c, const KfD
 __device__ __forceinline__ bool project_to_pixel(const CamConsts& c, const KfDev& kf, f3 gp, Proj* r) {
   const M34& T = kf.frame_T_global;
   r->local.z = tr_row(T.m[8], T.m[9], T.m[10], T.m[11], gp);
-#if !BSLAM_PROJECT_SINGLE_BRANCH
-  if (r->local.z <= 0.f) return false;
-#endif
   r->local.x = tr_row(T.m[0], T.m[1], T.m[2], T.m[3], gp);
   r->local.y = tr_row(T.m[4], T.m[5], T.m[6], T.m[7], gp);
   r->pxy = project(c.fx, c.fy, c.cx, c.cy, r->local);
   r->px = f2i(r->pxy.x);
   r->py = f2i(r->pxy.y);
-#if BSLAM_PROJECT_SINGLE_BRANCH
-  // one exit: a point behind the camera projects to garbage (finite or not) that the z test discards
+  // one exit (with the per-surfel work order a wave's lanes almost always agree, so early outs only cost exec-mask
+  // bookkeeping): a point behind the camera projects to garbage (finite or not) that the z test discards
   return (r->local.z > 0.f) & !(r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height);
-#else
-  return !(r->pxy.x < 0 || r->pxy.y < 0 || r->px >= c.width || r->py >= c.height);
-#endif
 }
 // Stage 2: the pixel's derived record.  The offset inside one keyframe's table fits 24 bits (v_mad_u32_u24, full rate) and is
 // added to the uniform base as a 32-bit offset (global_load with an SGPR base): no 64-bit vector arithmetic per gather.
@@ -577,7 +544,6 @@ __device__ __forceinline__ uint32_t raw_depth_of(const KfDev& kf, const Proj& r)
 // Stage 3: IsAssociatedWithPixel<false, true> BS/surfel_projection_nvcc_only.cuh:49-127 on the loaded record.
 __device__ __forceinline__ bool associate_with_record(const CamConsts& c, const KfDev& kf, f3 gn, PixelRecord rec, Proj* r) {
   const M34& T = kf.frame_T_global;
-#if BSLAM_ASSOC_SINGLE_BRANCH
   // all four tests evaluated, one branch: with the per-surfel work order a wave's lanes almost always agree, and 99.6 % of the
   // in-bounds pairs pass, so the early outs only cost exec-mask bookkeeping
   r->depth = rec.depth;
@@ -588,26 +554,13 @@ __device__ __forceinline__ bool associate_with_record(const CamConsts& c, const 
   const float sd = depth_stddev(r->nx, r->ny, r->depth, r->n_local, c.inv_baseline_fx);
   bool ok = rec.depth != 0.f;
   ok &= !(fabsf(r->local.z - r->depth) > kDepthTukey * sd);
+  // reference: (1.0f / Norm(local)) * Dot(local, n_local) > 0  (:107-111).  1 / |local| is a positive, finite, normal number
+  // for every |local| in [2^-126, 2^126] (and |local| >= local.z > 0 here), so the product has the sign of the dot product
+  // unless it underflows, which needs |dot| < 2^-23 * 2^-126 * |local|: the sign test is evaluated on the dot product directly
+  // (saves a sqrt and a division per pair).
   ok &= !(dot(r->local, r->n_local) > 0);
   ok &= !(dot(r->n_local, r->pixel_normal) < kCosNormalCompat);
   return ok;
-#else
-  if (rec.depth == 0.f) return false;
-  r->depth = rec.depth;
-  r->n_local = rot34(T, gn);
-  r->nx = nx_of(c, (float)r->px);
-  r->ny = ny_of(c, (float)r->py);
-  const float stddev = depth_stddev(r->nx, r->ny, r->depth, r->n_local, c.inv_baseline_fx);
-  if (fabsf(r->local.z - r->depth) > kDepthTukey * stddev) return false;
-  // reference: (1.0f / Norm(local)) * Dot(local, n_local) > 0  (:107-111).  1 / |local| is a positive,
-  // finite, normal number for every |local| in [2^-126, 2^126] (and |local| >= local.z > 0 here), so the
-  // product has the sign of the dot product unless it underflows, which needs |dot| < 2^-23 * 2^-126 * |local|:
-  // the sign test is evaluated on the dot product directly (saves a sqrt and a division per pair).
-  if (dot(r->local, r->n_local) > 0) return false;
-  r->pixel_normal = mk3(rec.nx, rec.ny, rec.nz);
-  if (dot(r->n_local, r->pixel_normal) < kCosNormalCompat) return false;
-  return true;
-#endif
 }
 // gp: global position, gn: unit global normal (already decoded).  Returns true when the surfel is
 // associated with the pixel it projects to.
@@ -878,24 +831,6 @@ __device__ __forceinline__ float dpp_add_xor1(float keep, float send) {   // qua
 }
 __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   const uint32_t lane = threadIdx.x & 63u;
-#ifndef BSLAM_TR_PERMLANE
-#define BSLAM_TR_PERMLANE 0
-#endif
-#if BSLAM_TR_PERMLANE
-  // v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b; v_permlane16_swap: the odd rows of 16 lanes of a <-> the
-  // even rows of b.  After swapping v[i] with v[i + N], a + b is "own kept value + partner's sent value" in every lane:
-  // two instructions per exchange instead of two selects, a ds_bpermute and an add.
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-#else
 #define BSLAM_TR_STEP(N, MASK)                                           \
   {                                                                      \
     const bool up = (lane & MASK) != 0;                                  \
@@ -908,7 +843,6 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   BSLAM_TR_STEP(16, 32)
   BSLAM_TR_STEP(8, 16)
 #undef BSLAM_TR_STEP
-#endif
   {
     const bool up = (lane & 8u) != 0;
 #pragma unroll

@@ -51,6 +51,7 @@ def host_lib():
     L.bsh_upload_keyframe_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u16p]
     L.bsh_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.bsh_set_scheme_end_tasks.argtypes = [C.c_void_p, C.c_int]
+    L.bsh_set_timings_file.argtypes = [C.c_void_p, C.c_char_p]
     L.bsh_keyframe_is_deleted.argtypes = [C.c_void_p, C.c_int]
     L.bsh_delete_keyframe.argtypes = [C.c_void_p, C.c_int]
     L.bsh_merge_keyframes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
@@ -370,6 +371,10 @@ class DirectBA:
     def set_options(self, batched_pose_optimization=True, pcg_gauge_keyframe=-1, texture_mode=abi.TEX_FIXED_POINT_1_8, scheme_end_tasks=True):
         self._check(self.L.bsh_set_options(self._ba, int(batched_pose_optimization), pcg_gauge_keyframe, texture_mode))
         self._check(self.L.bsh_set_scheme_end_tasks(self._ba, int(scheme_end_tasks)))
+
+    def set_timings_file(self, path):
+        """--save_timings: one block of BA_* lines per BA iteration (BS/direct_ba_alternating.cc:630-688); None stops."""
+        self._check(self.L.bsh_set_timings_file(self._ba, path.encode() if path else None))
 
     def CreateSurfelsForKeyframe(self, filter_new_surfels, kf_id):
         self._check(self.L.bsh_create_surfels_for_keyframe(self._ba, self.stream, int(filter_new_surfels), kf_id))

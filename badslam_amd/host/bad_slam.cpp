@@ -143,24 +143,24 @@ void BadSlam::PreprocessFrame(const u16* depth_image, const u8* rgb_image) {
   // the frame's final depth image is filtered_depth_buffer_A_ (:759)
 }
 
+// Motion model (BS/bad_slam.cc:903-951): the two start poses handed to the tracker.  Kept here as ONE short history of frame
+// poses relative to the base keyframe, newest last; the inter-frame motions are formed from it on demand.
+//   estimate 1: the last inter-frame motion applied once more to the last frame,
+//   estimate 2: the motion before that applied twice to the frame before the last (i.e. "ignore the last frame").
 void BadSlam::PredictFramePose(SE3f* estimate_1, SE3f* estimate_2) const {
-  const size_t stored_frames = base_kf_tr_frame_.size();
-  if (stored_frames == 0) throw std::logic_error("PredictFramePose without a motion model entry");
-  if (config_.use_motion_model) {
-    if (stored_frames >= 2) {   // constant motion
-      *estimate_1 = base_kf_tr_frame_[stored_frames - 1] * frame_tr_base_kf_[stored_frames - 2] * base_kf_tr_frame_[stored_frames - 1];
-    } else {
-      *estimate_1 = base_kf_tr_frame_[stored_frames - 1];
-    }
-    if (stored_frames >= 3) {   // constant motion without the last frame
-      const SE3f prev_frame_T_last_frame = frame_tr_base_kf_[stored_frames - 3] * base_kf_tr_frame_[stored_frames - 2];
-      *estimate_2 = base_kf_tr_frame_[stored_frames - 2] * prev_frame_T_last_frame * prev_frame_T_last_frame;
-    } else {
-      *estimate_2 = *estimate_1;
-    }
-  } else {
-    *estimate_1 = base_kf_tr_frame_[stored_frames - 1];
-    *estimate_2 = *estimate_1;
+  const std::vector<SE3f>& poses = base_kf_tr_frame_;
+  if (poses.empty()) throw std::logic_error("PredictFramePose without a motion model entry");
+  const size_t n = poses.size();
+  const SE3f& last = poses[n - 1];
+  *estimate_1 = last;
+  if (config_.use_motion_model && n >= 2) {
+    const SE3f step = poses[n - 2].Inverse() * last;        // previous frame -> last frame
+    *estimate_1 = last * step;
+  }
+  *estimate_2 = *estimate_1;
+  if (config_.use_motion_model && n >= 3) {
+    const SE3f older_step = poses[n - 3].Inverse() * poses[n - 2];
+    *estimate_2 = poses[n - 2] * older_step * older_step;
   }
 }
 
@@ -177,12 +177,10 @@ void BadSlam::RunOdometry(int frame_index) {
                      estimate_2, &base_T_frame_estimate, nullptr);
   FramePose(frame_index) = base_kf_global_T_frame_ * base_T_frame_estimate;
   last_frame_index_ = frame_index;
-  if (base_kf_tr_frame_.size() >= 3) {
-    base_kf_tr_frame_.erase(base_kf_tr_frame_.begin());
-    frame_tr_base_kf_.erase(frame_tr_base_kf_.begin());
-  }
+  // the history holds at most three frames
+  constexpr size_t kMotionModelFrames = 3;
   base_kf_tr_frame_.push_back(base_T_frame_estimate);
-  frame_tr_base_kf_.push_back(base_T_frame_estimate.Inverse());
+  if (base_kf_tr_frame_.size() > kMotionModelFrames) base_kf_tr_frame_.erase(base_kf_tr_frame_.begin(), base_kf_tr_frame_.end() - kMotionModelFrames);
 }
 
 std::shared_ptr<Keyframe> BadSlam::CreateKeyframe(int frame_index) {
@@ -198,17 +196,14 @@ std::shared_ptr<Keyframe> BadSlam::CreateKeyframe(int frame_index) {
   direct_ba_->AddKeyframe(new_keyframe);   // AddKeyframeToBA without a loop detector (:1120-1158)
   const int keyframes_added = static_cast<int>(direct_ba_->keyframes().size());
 
-  // re-base the motion model on the new keyframe (:1054-1066)
-  for (int i = 0; i < static_cast<int>(frame_tr_base_kf_.size()) - 1; ++i) {
-    frame_tr_base_kf_[i] = frame_tr_base_kf_[i] * base_kf_tr_frame_.back();
-    base_kf_tr_frame_[i] = frame_tr_base_kf_.back() * base_kf_tr_frame_[i];
-  }
-  if (frame_tr_base_kf_.empty()) {
+  // The new keyframe is the frame the history ends with: from now on poses are expressed relative to it
+  // (what BS/bad_slam.cc:1054-1066 does to its two arrays).
+  if (base_kf_tr_frame_.empty()) {
     base_kf_tr_frame_.push_back(SE3f());
-    frame_tr_base_kf_.push_back(SE3f());
   } else {
-    base_kf_tr_frame_.back() = SE3f();
-    frame_tr_base_kf_.back() = SE3f();
+    const SE3f new_base_T_old_base = base_kf_tr_frame_.back().Inverse();
+    for (SE3f& pose : base_kf_tr_frame_) pose = new_base_T_old_base * pose;
+    base_kf_tr_frame_.back() = SE3f();   // exactly the identity, not a product that rounds to it
   }
   if (!config_.estimate_poses) return new_keyframe;
 

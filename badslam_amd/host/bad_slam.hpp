@@ -65,7 +65,7 @@ class BadSlam {
 
   Keyframe* base_kf_ = nullptr;
   SE3f base_kf_global_T_frame_;
-  std::vector<SE3f> base_kf_tr_frame_, frame_tr_base_kf_;   // motion model: the last (up to three) frames relative to the base keyframe
+  std::vector<SE3f> base_kf_tr_frame_;   // motion model: poses of the last (up to three) frames relative to the base keyframe, newest last
   std::vector<SE3f> frame_global_T_frame_;
   int last_frame_index_ = -1;
   int num_planned_ba_iterations_ = 0;

@@ -2,6 +2,8 @@
 // FFIs can drive the C++ host class.  Exceptions never cross the boundary: they are turned into a
 // negative return code + bsh_last_error().
 #include <cstring>
+#include <fstream>
+#include <map>
 #include <memory>
 #include <string>
 
@@ -40,7 +42,8 @@ void* bsh_create(int max_surfel_count, float raw_to_float_depth, float baseline_
   }
 }
 
-void bsh_destroy(void* ba) { delete static_cast<DirectBA*>(ba); }
+static std::map<void*, std::unique_ptr<std::ofstream>> g_timings;
+void bsh_destroy(void* ba) { delete static_cast<DirectBA*>(ba); g_timings.erase(ba); }
 
 // the kernel library's context of this DirectBA (bslam_profile_* on the BA's own launches)
 void* bsh_context(void* ba) { return static_cast<DirectBA*>(ba)->context(); }
@@ -171,6 +174,21 @@ int bsh_set_options(void* ba, int batched_pose_optimization, int pcg_gauge_keyfr
     b->SetBatchedPoseOptimization(batched_pose_optimization != 0);
     b->SetPCGGaugeKeyframe(pcg_gauge_keyframe);
     b->SetTextureMode(texture_mode);
+  });
+}
+// --save_timings (BS/main.cc:660-662): the BA phase timing lines of BS/direct_ba_alternating.cc:630-688 go to `path`
+// (nullptr / "": stop).  The stream lives as long as the DirectBA it was set on.
+int bsh_set_timings_file(void* ba, const char* path) {
+  BSH_TRY({
+    DirectBA* b = static_cast<DirectBA*>(ba);
+    b->SetTimingsStream(nullptr);
+    g_timings.erase(ba);
+    if (path && *path) {
+      auto f = std::make_unique<std::ofstream>(path);
+      if (!*f) throw std::runtime_error(std::string("cannot open ") + path);
+      b->SetTimingsStream(f.get());
+      g_timings[ba] = std::move(f);
+    }
   });
 }
 int bsh_set_allreduce(void* ba, bslam_allreduce_fn fn, void* user) { BSH_TRY(static_cast<DirectBA*>(ba)->SetAllReduce(fn, user)); }

@@ -489,6 +489,7 @@ void DirectBA::MergeAndCompact(hipStream_t stream, const std::vector<u32>& keyfr
   const bslam_depth_params dp = depth_params();
   const bslam_buffer2d surfels = surfels_->ToPod(), active = active_surfels_->ToPod();
   u32 surfel_count = surfel_count_;
+  HIP_OR_THROW(hipEventRecord(ev_[10], stream));   // "BA initial surfel merge" (BS/direct_ba_alternating.cc:486-509)
   for (u32 id : keyframe_ids) {
     const auto& kf = keyframes_[id];
     if (!kf) continue;
@@ -497,9 +498,11 @@ void DirectBA::MergeAndCompact(hipStream_t stream, const std::vector<u32>& keyfr
                                                        &surfel_count),
           "bslam_determine_supporting_surfels_and_merge");
   }
+  HIP_OR_THROW(hipEventRecord(ev_[11], stream));
   Lock();
   surfel_count_ = surfel_count;
   Unlock();
+  HIP_OR_THROW(hipEventRecord(ev_[12], stream));   // "BA surfel compaction" (:511-533)
   if (!keyframe_ids.empty()) {
     u32 surfels_size = surfels_size_;
     Check(bslam_compact_surfels(ctx_, stream, surfel_count_, &surfels_size, &surfels, &active), "bslam_compact_surfels");
@@ -507,6 +510,7 @@ void DirectBA::MergeAndCompact(hipStream_t stream, const std::vector<u32>& keyfr
     surfels_size_ = surfels_size;
     Unlock();
   }
+  HIP_OR_THROW(hipEventRecord(ev_[13], stream));
 }
 
 // BS/direct_ba.cc:566-653
@@ -669,7 +673,9 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         }
       }
       Unlock();
+      HIP_OR_THROW(hipEventRecord(ev_[8], stream));
       for (u32 id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[id]);
+      HIP_OR_THROW(hipEventRecord(ev_[9], stream));
     }
 
     const bslam_depth_params dp = depth_params();
@@ -747,6 +753,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
 
     // --- INTRINSICS OPTIMIZATION (:579-624) ---
     if (optimize_depth_intrinsics || optimize_color_intrinsics) {
+      HIP_OR_THROW(hipEventRecord(ev_[14], stream));
       std::vector<bslam_keyframe_view> all_views = KeyframeViews();   // poses may have changed above
       bslam_camera4f out_color = color_cam, out_depth = depth_cam;
       float out_a = a_;
@@ -763,18 +770,25 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         }
         Unlock();
       }
+      HIP_OR_THROW(hipEventRecord(ev_[15], stream));
     }
 
-    // --- TIMING (:626-689), same line format as --save_timings ---
+    // --- TIMING (:626-689), same line format and order as --save_timings ---
     if (timings_stream_) {
       HIP_OR_THROW(hipStreamSynchronize(stream));
       float ms = 0.f;
       *timings_stream_ << "BA_count " << fixed_ba_iteration_count << " inner_iteration " << iteration << " keyframe_count " << keyframes_.size()
                        << " surfel_count " << surfel_count_ << std::endl;
+      if (optimize_geometry && do_surfel_updates) { HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[8], ev_[9])); *timings_stream_ << "BA_surfel_creation " << ms << std::endl; }
       HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
       *timings_stream_ << "BA_surfel_activation " << ms << std::endl;
       if (optimize_geometry) { HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[2], ev_[3])); *timings_stream_ << "BA_geometry_optimization " << ms << std::endl; }
+      if (do_surfel_updates) {
+        HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[10], ev_[11])); *timings_stream_ << "BA_initial_surfel_merge " << ms << std::endl;
+        HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[12], ev_[13])); *timings_stream_ << "BA_surfel_compaction " << ms << std::endl;
+      }
       if (optimize_poses) { HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[4], ev_[5])); *timings_stream_ << "BA_pose_optimization " << ms << std::endl; }
+      if (optimize_depth_intrinsics || optimize_color_intrinsics) { HIP_OR_THROW(hipEventElapsedTime(&ms, ev_[14], ev_[15])); *timings_stream_ << "BA_intrinsics_optimization " << ms << std::endl; }
     }
 
     // --- CONVERGENCE (:692-717) ---

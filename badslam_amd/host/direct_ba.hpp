@@ -315,7 +315,9 @@ class DirectBA {
   bslam_allreduce_fn allreduce_ = nullptr;
   void* allreduce_user_ = nullptr;
   // phase timing (BS/direct_ba.h:513-532)
-  hipEvent_t ev_[8];
+  // phase timing events of a BA iteration (--save_timings lines): [0,1] activation, [2,3] geometry, [4,5] poses, [6,7] PCG,
+  // [8,9] surfel creation, [10,11] initial surfel merge, [12,13] surfel compaction, [14,15] intrinsics
+  hipEvent_t ev_[16];
 };
 
 }  // namespace bslam_host

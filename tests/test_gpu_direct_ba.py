@@ -92,7 +92,7 @@ def test_geometry_optimization_with_photometric_residual(oracle, use_pcg):
         assert abs(oc - correct) <= 0.002 * (oc + of), (oc, of, correct, fails)
 
 
-def test_do_surfel_updates_lifecycle_through_the_host_loop(oracle):
+def test_do_surfel_updates_lifecycle_through_the_host_loop(oracle, tmp_path):
     """BundleAdjustment(do_surfel_updates = true): the BA creates (filtered), merges, deletes and compacts the surfels
     itself (BS/direct_ba_alternating.cc:396-533, BS/direct_ba.cc:566-653).  Same geometry known-answer as above, but
     starting without any surfel."""
@@ -100,8 +100,19 @@ def test_do_surfel_updates_lifecycle_through_the_host_loop(oracle):
     scene.surfels_size = 0
     ba = make_ba(scene, pcg_gauge_keyframe=0)
     assert ba.surfels_size() == 0
+    timings = str(tmp_path / "timings.txt")
+    ba.set_timings_file(timings)
     for _ in range(10):
         ba.BundleAdjustment(False, False, True, False, True, 10, 10, False, 0, 0, True)
+    ba.set_timings_file(None)
+    # --save_timings lines of one BA iteration with surfel updates and geometry optimisation, in the reference's order
+    # (BS/direct_ba_alternating.cc:630-688): header, creation, activation, geometry, merge, compaction
+    lines = open(timings).read().split("\n")
+    assert lines[0].startswith("BA_count ") and " inner_iteration 0 " in lines[0] and " keyframe_count 1 " in lines[0]
+    assert [ln.split()[0] for ln in lines[1:6]] == ["BA_surfel_creation", "BA_surfel_activation", "BA_geometry_optimization",
+                                                  "BA_initial_surfel_merge", "BA_surfel_compaction"]
+    assert all(float(ln.split()[1]) >= 0.0 for ln in lines[1:6])
+    assert sum(ln.startswith("BA_count") for ln in lines) >= 10
     n = ba.surfels_size()
     assert n > 250000, n
     surf = ba.GetSurfels(8)

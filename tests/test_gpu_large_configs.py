@@ -109,6 +109,59 @@ def test_configs2_photometric_300_keyframes_properties_and_oracle(oracle):
         assert np.abs(full[k, 21:27] - b64).max() <= 1e-4 * max(np.abs(b64).max(), 1e-3 * np.abs(H64).max()), k
 
 
+def oracle_coefficients(dev, k, surf, use_desc):
+    """H, b (float64 sums of the oracle's fp32 terms) and the residual count of keyframe k over all surfels, on data copied back
+    from the device."""
+    from tests import bso
+    L = bso.lib()
+    sb = bso.np_buffer2d(surf)
+    cf = bso.np_buffer2d(dev.stack.cfactor)
+    dp = abi.DepthParams(cf, 0.0, float(dev.stack.raw_to_float_depth), dev.stack.baseline_fx, dev.stack.cell)
+    depth, normals, radius, color = dev.host_keyframe(k)
+    _, M, _ = dev.stack.pose(k)
+    H, b = np.zeros(21, np.float32), np.zeros(6, np.float32)
+    H64, b64 = np.zeros(21, np.float64), np.zeros(6, np.float64)
+    count, cost = C.c_uint32(), C.c_float()
+    L.bso_accumulate_pose_estimation_coeffs(1, int(use_desc), C.byref(dev.stack.camera), C.byref(dev.stack.camera), C.byref(dp), C.byref(bso.np_buffer2d(depth)),
+                                            C.byref(bso.np_buffer2d(normals)), C.byref(bso.np_buffer2d(color)), C.byref(M), dev.surfels_size, C.byref(sb),
+                                            abi.TEX_FIXED_POINT_1_8, C.byref(count), C.byref(cost), bso.fptr(H), bso.fptr(b),
+                                            H64.ctypes.data_as(P(C.c_double)), b64.ctypes.data_as(P(C.c_double)), None)
+    return H64, b64, count.value
+
+
+def test_trajectory_stack_300_keyframes_culling_properties_and_oracle(oracle):
+    """The smooth-trajectory stack of SURVEY.md 8(d) at configs[2] size (300 keyframes, 5.76 M surfels, depth + descriptor
+    residuals): a keyframe sees about a tenth of the room, so most (work slot, keyframe) pairs are culled.  Determinism and
+    additivity as on the dense stack, culling on = culling off bit for bit, and the oracle's H / b / counts on three keyframes."""
+    import torch
+    K = 300
+    dev = synthetic.TorchStack(K, "cuda:0", kind="trajectory")
+    assert dev.surfels_size == 19200 * K
+    run = Runner(dev, use_desc=True)
+    act = run.activation()
+    assert int(act.sum()) > 0.99 * dev.surfels_size
+    run.geometry()
+    assert torch.equal(run.activation(), act)
+    run.geometry()
+    t, c = C.c_uint64(), C.c_uint64()
+    badslam_amd.check(run.L.bslam_profile_enable(run.ctx.handle, 1))
+    badslam_amd.check(run.L.bslam_debug_cull_stats(run.ctx.handle, C.byref(t), C.byref(c)))
+    full, cnt = check_additive_and_deterministic(run, 1e-4)
+    badslam_amd.check(run.L.bslam_debug_cull_stats(run.ctx.handle, C.byref(t), C.byref(c)))
+    badslam_amd.check(run.L.bslam_profile_enable(run.ctx.handle, 0))
+    assert c.value > 0.8 * t.value, (c.value, t.value)          # four fifths of the (slot, keyframe) pairs never run
+    badslam_amd.check(run.L.bslam_set_culling(run.ctx.handle, 0))
+    off, cnt_off = run.coeffs()
+    badslam_amd.check(run.L.bslam_set_culling(run.ctx.handle, 1))
+    assert np.array_equal(full.view(np.uint32), off.view(np.uint32)) and np.array_equal(cnt, cnt_off)
+    surf = np.ascontiguousarray(dev.surfels.cpu().numpy())
+    for k in (0, 149, 299):
+        H64, b64, count = oracle_coefficients(dev, k, surf, True)
+        assert count == cnt[k], (k, count, cnt[k])
+        assert np.abs(full[k, :21] - H64).max() <= 1e-4 * np.abs(H64).max(), k
+        assert np.abs(full[k, 21:27] - b64).max() <= 1e-4 * max(np.abs(b64).max(), 1e-3 * np.abs(H64).max()), k
+
+
 def test_configs4_geometry_1000_keyframes_20m_surfels_properties():
     """configs[4] size on one GPU: 1000 keyframes, 19.2 M surfels, depth residuals only (3.1 GB of keyframe images, 2.5 GB of
     derived records, 1.3 GB of surfels: 288 GB of HBM make the 8-GPU workload a single-card case)."""
