@@ -298,6 +298,7 @@ static int make_schedule(bslam_context* ctx, hipStream_t stream, const bslam_buf
     if (!ctx->perm_ready) BSLAM_HIP_TRY(hipEventCreateWithFlags(&ctx->perm_ready, hipEventDisableTiming));
     BSLAM_HIP_TRY(hipEventRecord(ctx->perm_ready, stream));
     ctx->perm_stream = stream;
+    ++ctx->perm_serial;
     ctx->perm_key_ptr = surfels->address;
     ctx->perm_key_size = surfels_size;
     ctx->perm_key_pitch = surfels->pitch;
@@ -342,11 +343,11 @@ struct SurfelWork {
   const uint32_t* perm;     // position in `rows` -> caller's column, or nullptr
 };
 static int prepare_surfels(bslam_context* ctx, hipStream_t stream, const bslam_buffer2d* surfels, uint32_t surfels_size, int R, int keyframe_count, SurfelWork* w,
-                           bool need_descriptor_rows = true) {
+                           bool need_descriptor_rows = true, bool same_surfels_as_last_call = false) {
   int rc = make_schedule(ctx, stream, surfels, surfels_size, R, &w->sc, keyframe_count, &w->perm);
   if (rc) return rc;
   w->rows = surfel_rows(surfels, surfels_size);
-  if (!w->perm) return BSLAM_OK;
+  if (!w->perm) { ctx->sorted_key_ptr = nullptr; return BSLAM_OK; }
   const size_t pitch = ((size_t)surfels_size + 63) & ~(size_t)63;
   if ((rc = ctx->sorted_rows.reserve(7 * pitch * sizeof(float)))) return rc;
   float* out = (float*)ctx->sorted_rows.ptr;
@@ -358,13 +359,21 @@ static int prepare_surfels(bslam_context* ctx, hipStream_t stream, const bslam_b
   }
   // the copy costs a scattered 4-byte read per row and surfel: rows the call's kernels never read (radius, descriptors in a
   // geometry-only call) are left out
-  if (need_descriptor_rows)
+  const int copy_rows = need_descriptor_rows ? 7 : 4;
+  const bool reuse = same_surfels_as_last_call && ctx->sorted_key_ptr == surfels->address && ctx->sorted_key_size == surfels_size &&
+                     ctx->sorted_key_pitch == surfels->pitch && ctx->sorted_key_rows >= copy_rows && ctx->sorted_key_bounds == (bounds != nullptr) &&
+                     ctx->sorted_key_perm_serial == ctx->perm_serial;
+  if (reuse) {
+    // K = 300 photometric PCG: 0.47 ms per PCGStep1 call, 8.5 of the 325 ms of a BA iteration
+  } else if (need_descriptor_rows)
     hipLaunchKernelGGL(permute_surfel_rows_kernel<7>, dim3(w->sc.granules), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
                        surfels->pitch / sizeof(float), out, pitch, bounds);
   else
     hipLaunchKernelGGL(permute_surfel_rows_kernel<4>, dim3(w->sc.granules), dim3(256), 0, stream, w->perm, surfels_size, (const float*)surfels->address,
                        surfels->pitch / sizeof(float), out, pitch, bounds);
   BSLAM_HIP_TRY(hipGetLastError());
+  ctx->sorted_key_ptr = surfels->address; ctx->sorted_key_size = surfels_size; ctx->sorted_key_pitch = surfels->pitch;
+  if (!reuse) { ctx->sorted_key_rows = copy_rows; ctx->sorted_key_bounds = bounds != nullptr; ctx->sorted_key_perm_serial = ctx->perm_serial; }
   w->sc.bounds = bounds;
   w->rows.x = out; w->rows.y = out + pitch; w->rows.z = out + 2 * pitch;
   w->rows.normal = (const uint32_t*)(out + 3 * pitch);

@@ -154,6 +154,15 @@ struct bslam_context {
   bslam::Slab perm;          // per-surfel Morton order (+ sort scratch), cached like `order`
   bslam::Slab sorted_rows;   // the seven persistent surfel rows in that order, rebuilt by every call that uses it
   bslam::Slab bounds;        // float4[2 * granules]: bounding box of every granule of the sorted copy, rebuilt with it
+  // what the sorted copy holds (prepare_surfels): PCGStep1 re-uses the copy PCGInit / the previous PCGStep1 of the same solve
+  // made -- the surfels do not change inside a solve (BS/direct_ba_pcg.cc:339-425) -- every other call rebuilds it
+  const void* sorted_key_ptr = nullptr;
+  uint32_t sorted_key_size = 0;
+  size_t sorted_key_pitch = 0;
+  int sorted_key_rows = 0;
+  bool sorted_key_bounds = false;
+  uint64_t sorted_key_perm_serial = 0;   // the permutation the copy was made with
+  uint64_t perm_serial = 0;              // counts rebuilds of `perm`
   bslam::Slab vis;           // uint32[chunks][slots]: keyframes of a chunk a work slot visited in the last pose_accumulate launch
   bool culling = true;       // block-level frustum culling in the pair kernels (bslam_set_culling)
   const void* perm_key_ptr = nullptr;

@@ -616,7 +616,11 @@ int bslam_pcg_init2(bslam_context* ctx, void* stream, const bslam_pcg_layout* la
 
 /* Replaces the K x PCGStep1CUDA loop incl. its alpha_d / g memsets
  * (BS/kernels.h:430-452, BS/direct_ba_pcg.cc:383-425).  Quirk Q7 (the epsilon
- * term added once per keyframe) is reproduced. */
+ * term added once per keyframe) is reproduced.  A step belongs to the solve its
+ * bslam_pcg_init started: the surfel buffer must not have been modified by the caller
+ * since that call (the reference's solve does not touch the surfels either,
+ * BS/direct_ba_pcg.cc:339-425) -- the library re-uses its sorted copy of the surfel rows
+ * when the preceding call on this context was the init or a step on the same buffer. */
 int bslam_pcg_step1(
     bslam_context* ctx, void* stream, const bslam_pcg_layout* layout,
     const bslam_camera4f* color_camera, const bslam_camera4f* depth_camera,
