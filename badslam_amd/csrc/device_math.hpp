@@ -396,44 +396,42 @@ __device__ __forceinline__ void grad_filter(const LumaQuad& t, const GradFootpri
 // raw_descriptor_residual + descriptor_jacobian_wrt_projected_position sharing their gathers, in two steps: the three
 // footprints and the three gathers first (DescSamples: the loads are in flight when it returns), the filters later -- so
 // that a kernel can issue the gathers of several surfels before it waits for the first.
+// Inside the image the gradient's footprint (BS/cost_function.cuh:200-211: ix = int(max(0, x - 0.5)), tx = clamp(x - 0.5 - ix, 0, 1))
+// IS the sample's: ix = floor(x - 0.5) and tx = the unquantised fraction, bit for bit (the same subtraction).  Only in the
+// half-pixel border strip does a gradient read another quad than its sample; that rarely taken path asks the caller for the
+// sample positions again (`sample_points`: a callable filling f2[3] = {centre, tangent point 1, tangent point 2}, recomputed
+// from what the kernel holds anyway) instead of carrying a second set of footprints through every pair.
 struct DescSamples {
   TexFootprint f[3];
-  GradFootprint g[3];
   uint32_t q[3];
 };
 __device__ __forceinline__ DescSamples descriptor_samples_issue(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2) {
   DescSamples d;
   const f2 pts[3] = {cp, t1, t2};
-  // Inside the image the gradient's footprint (BS/cost_function.cuh:200-211: ix = int(max(0, x - 0.5)), tx = clamp(x - 0.5 - ix, 0, 1))
-  // IS the sample's: ix = floor(x - 0.5) and tx = the unquantised fraction, bit for bit (the same subtraction); only the
-  // half-pixel border strip needs the general form (one rarely taken block for all three samples).
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    d.f[k] = tex_footprint(c, pts[k].x, pts[k].y);
-    d.g[k].ix = d.f[k].i; d.g[k].iy = d.f[k].j; d.g[k].tx = d.f[k].ua; d.g[k].ty = d.f[k].ub;
-  }
-  if (!(d.f[0].interior & d.f[1].interior & d.f[2].interior)) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) d.g[k] = grad_footprint(c, pts[k]);
-  }
+  for (int k = 0; k < 3; ++k) d.f[k] = tex_footprint(c, pts[k].x, pts[k].y);
 #pragma unroll
   for (int k = 0; k < 3; ++k) d.q[k] = quad_at(kf, c, d.f[k].i, d.f[k].j);
   return d;
 }
-__device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const CamConsts& c, const DescSamples& d, float d1, float d2,
+template <class SamplePoints>
+__device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const CamConsts& c, const DescSamples& d, float d1, float d2, SamplePoints&& sample_points,
                                                           float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
   float val[3], gx[3], gy[3];   // byte units
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const LumaQuad t = unpack_quad_bytes(d.q[k]);
     val[k] = bilinear_bytes(t, d.f[k].a, d.f[k].b);
-    bilinear_gradient_bytes(t, d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
+    bilinear_gradient_bytes(t, d.f[k].ua, d.f[k].ub, &gx[k], &gy[k]);
   }
-  // only in the half-pixel border strip does a gradient read another quad than its sample
-  if ((d.g[0].ix != d.f[0].i) | (d.g[0].iy != d.f[0].j) | (d.g[1].ix != d.f[1].i) | (d.g[1].iy != d.f[1].j) | (d.g[2].ix != d.f[2].i) | (d.g[2].iy != d.f[2].j)) {
+  if (!(d.f[0].interior & d.f[1].interior & d.f[2].interior)) {   // some sample's 2x2 footprint touches the image border
+    f2 pts[3];
+    sample_points(pts);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      bilinear_gradient_bytes(unpack_quad_bytes(quad_at(kf, c, d.g[k].ix, d.g[k].iy)), d.g[k].tx, d.g[k].ty, &gx[k], &gy[k]);
+    for (int k = 0; k < 3; ++k) {
+      const GradFootprint g = grad_footprint(c, pts[k]);
+      bilinear_gradient_bytes(unpack_quad_bytes(quad_at(kf, c, g.ix, g.iy)), g.tx, g.ty, &gx[k], &gy[k]);
+    }
   }
   *r1 = __builtin_fmaf(kDescScale, val[1] - val[0], -d1);
   *r2 = __builtin_fmaf(kDescScale, val[2] - val[0], -d2);
@@ -445,7 +443,7 @@ __device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const
 __device__ __forceinline__ void descriptor_residual_and_jacobian(const KfDev& kf, const CamConsts& c, f2 cp, f2 t1, f2 t2, float d1, float d2,
                                                                  float* r1, float* r2, float* gx1, float* gy1, float* gx2, float* gy2) {
   const DescSamples d = descriptor_samples_issue(kf, c, cp, t1, t2);
-  descriptor_samples_finish(kf, c, d, d1, d2, r1, r2, gx1, gy1, gx2, gy2);
+  descriptor_samples_finish(kf, c, d, d1, d2, [&](f2 (&pts)[3]) { pts[0] = cp; pts[1] = t1; pts[2] = t2; }, r1, r2, gx1, gy1, gx2, gy2);
 }
 
 // BS/surfel_projection.cuh:196-207
@@ -660,6 +658,18 @@ __device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, fl
   j[2] = gx;
   j[3] = gy;
 }
+
+// An accumulator zeroed by its own opaque instruction.  Written as `x = 0.f` the optimiser knows all accumulators of a set to be one
+// value: it folds the first fma(a, b, 0) into a multiply and then materialises the zeros a second time, as copies, for the
+// lanes that skip that term (pose kernel: 62 v_mov per keyframe and thread instead of 27).
+#ifndef BSLAM_INDEPENDENT_ZEROS
+#define BSLAM_INDEPENDENT_ZEROS 1
+#endif
+#if BSLAM_INDEPENDENT_ZEROS
+#define BSLAM_ZERO(x) asm volatile("v_mov_b32 %0, 0" : "=v"(x))
+#else
+#define BSLAM_ZERO(x) ((x) = 0.f)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // XCD-aware work schedule.  Surfels are handled in granules of 256 consecutive columns.  The

@@ -542,13 +542,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     for (int r = 0; r < R; ++r) {
       Proj p;
       DescSamples ds;
+      f2 color_pxy, t1, t2;   // the three sample positions of the descriptor residual
       bool has_desc = false;
       if constexpr (kPass == 1) {
         // the three quad gathers of the descriptor samples do not depend on the pixel record: issued with the record gather,
         // before the association test (see pose_accumulate_kernel)
         if (!on[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
-        f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         project_tangent_points(tp1[r], tp2[r], kf.frame_T_global, c, &t1, &t2);
         ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         }
         if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+          descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; }, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           const float jp1 = descriptor_position_jacobian(gx1, gy1, c.cfx, c.cfy, rn, p.local);
           const float jp2 = descriptor_position_jacobian(gx2, gy2, c.cfx, c.cfy, rn, p.local);
           const float jd = -1.f;

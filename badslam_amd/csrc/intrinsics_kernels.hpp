@@ -64,13 +64,13 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
     for (int r = 0; r < kIntrR; ++r) {
       Proj p;
       DescSamples ds;
+      f2 color_pxy, t1, t2;   // the three sample positions of the descriptor residual
       bool has_desc = false;
       if constexpr (kColorIntr) {
         // the quad gathers of the descriptor samples are issued with the record gather, before the association test
         // (see pose_accumulate_kernel)
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
-        f2 color_pxy, t1, t2;
         has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         tangent_projections(gp[r], gn[r], r2[r], kf.frame_T_global, c, &t1, &t2);
         ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kIntrThreads) void intrinsics_accumulate_kernel(
       if (kColorIntr) {                                           // :120-158, 198-216
         if (has_desc) {
           float r1, rr2, gx1, gy1, gx2, gy2;
-          descriptor_samples_finish(kf, c, ds, d1[r], d2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+          descriptor_samples_finish(kf, c, ds, d1[r], d2[r], [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; }, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
           float j1[4], j2[4];
           color_intrinsics_jacobian(gx1, gy1, nx, ny, j1);
           color_intrinsics_jacobian(gx2, gy2, nx, ny, j2);

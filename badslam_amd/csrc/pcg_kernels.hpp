@@ -152,10 +152,9 @@ struct DescTerms {
 
 // In two steps around the association test: the sample positions depend on the surfel and the pose only, so their three quad
 // gathers are issued together with the record gather (see pose_accumulate_kernel); the filters run after the test.
-__device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c, const KfDev& kf, f3 tp1, f3 tp2, f2 color_pxy) {
-  f2 t1, t2;
-  project_tangent_points(tp1, tp2, kf.frame_T_global, c, &t1, &t2);
-  return descriptor_samples_issue(kf, c, color_pxy, t1, t2);
+__device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c, const KfDev& kf, f3 tp1, f3 tp2, f2 color_pxy, f2* t1, f2* t2) {
+  project_tangent_points(tp1, tp2, kf.frame_T_global, c, t1, t2);
+  return descriptor_samples_issue(kf, c, color_pxy, *t1, *t2);
 }
 
 // Photometric variants: per-surfel constants that a pair only reads (normal, the two tangent sample points, descriptors, and
@@ -164,9 +163,10 @@ __device__ __forceinline__ DescSamples descriptor_terms_issue(const CamConsts& c
 // per pair.
 constexpr int kPcgStateComps = 14;   // 0-2 normal, 3-5 / 6-8 tangent points, 9-10 descriptor, 11-13 p entries (step 1)
 #define BSLAM_PCG_ST(r, comp) state[((r) * kPcgStateComps + (comp)) * kPcgThreads + threadIdx.x]
-__device__ __forceinline__ DescTerms descriptor_terms_finish(const CamConsts& c, const KfDev& kf, const DescSamples& ds, float d1, float d2) {
+template <class SamplePoints>
+__device__ __forceinline__ DescTerms descriptor_terms_finish(const CamConsts& c, const KfDev& kf, const DescSamples& ds, float d1, float d2, SamplePoints&& sample_points) {
   DescTerms t;
-  descriptor_samples_finish(kf, c, ds, d1, d2, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
+  descriptor_samples_finish(kf, c, ds, d1, d2, sample_points, &t.r1, &t.r2, &t.gx1, &t.gy1, &t.gx2, &t.gy2);
   t.gx1 *= c.cfx; t.gx2 *= c.cfx;
   t.gy1 *= c.cfy; t.gy2 *= c.cfy;
   t.w1 = desc_weight(t.r1);
@@ -227,20 +227,20 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pose[kPcgPoseRow];
 #pragma unroll
-    for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = 0.f;
+    for (int i = 0; i < kPcgPoseRow; ++i) BSLAM_ZERO(pose[i]);   // independent zeros: see pose_accumulate_kernel
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
       DescSamples ds;
+      f2 color_pxy, t1, t2;   // the three sample positions of the descriptor residual
       bool has_desc = false;
       if constexpr (kDesc) {
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
-        f2 color_pxy;
         has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),
-                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy);
+                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy, &t1, &t2);
         asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
         if (!associate_with_record(c, kf, mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)), rec, &p)) continue;
       } else {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       if (kDesc) {                                               // :330-511
         visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10));
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });
         const f3 ls = p.local;
         if (P.optimize_geometry) {                               // :364-399
           const float jp1 = descriptor_position_jacobian(t.gx1, t.gy1, 1.f, 1.f, rn, ls);   // gx, gy already carry fx, fy
@@ -494,20 +494,23 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
     if (opt_pose) for (int j = 0; j < 6; ++j) pp[j] = P.p[kf_idx + j];
     float pose[kPcgPoseRow];   // 6 live columns
 #pragma unroll
-    for (int i = 0; i < kPcgPoseRow; ++i) pose[i] = 0.f;
+    for (int i = 0; i < kPcgPoseRow; ++i) {
+      if (i < 6) BSLAM_ZERO(pose[i]);   // independent zeros: see pose_accumulate_kernel
+      else pose[i] = 0.f;
+    }
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
       DescSamples ds;
+      f2 color_pxy, t1, t2;   // the three sample positions of the descriptor residual
       bool has_desc = false;
       if constexpr (kDesc) {
         if (!valid[r] || !project_to_pixel(c, kf, gp[r], &p)) continue;
         const PixelRecord rec = load_record(c, kf, p);
-        f2 color_pxy;
         has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
         ds = descriptor_terms_issue(c, kf, mk3(BSLAM_PCG_ST(r, 3), BSLAM_PCG_ST(r, 4), BSLAM_PCG_ST(r, 5)),
-                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy);
+                                    mk3(BSLAM_PCG_ST(r, 6), BSLAM_PCG_ST(r, 7), BSLAM_PCG_ST(r, 8)), color_pxy, &t1, &t2);
         asm volatile("" ::: "memory");   // the gathers stay in front of the branches of the association test
         if (!associate_with_record(c, kf, mk3(BSLAM_PCG_ST(r, 0), BSLAM_PCG_ST(r, 1), BSLAM_PCG_ST(r, 2)), rec, &p)) continue;
       } else {
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       if (kDesc) {
         visible = visible && has_desc;
         if (!visible) continue;
-        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10));
+        const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });
         const f3 ls = p.local;
         float sum_1 = 0, sum_2 = 0, gj1 = 0, gj2 = 0;
         float J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};

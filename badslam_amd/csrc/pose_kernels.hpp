@@ -184,8 +184,14 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     todo &= todo - 1;
     const KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
     float acc[kRow];
+    // Every live accumulator is zeroed by its own opaque instruction.  Written as acc[i] = 0.f the optimiser knows all of
+    // them to be one value: it folds the first surfel's fma(wj, J, 0) into a multiply and then has to materialise the zeros a
+    // second time, as copies, for the lanes that skip that surfel (62 v_mov per keyframe and thread instead of 27).
 #pragma unroll
-    for (int i = 0; i < kRow; ++i) acc[i] = 0.f;
+    for (int i = 0; i < kRow; ++i) {
+      if (i < (kCost ? kRowCost + 1 : kRowCost)) BSLAM_ZERO(acc[i]);
+      else acc[i] = 0.f;
+    }
     // residual count of the wave: formed from ballots at the points where the lanes have reconverged (s_bcnt1 on the mask: no
     // VALU, and one column less in the reduction below); uniform
     uint32_t count = 0;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
       do {
         Proj p;
         DescSamples ds;
+        f2 color_pxy, t1, t2;   // the three sample positions of the descriptor residual
         bool has_desc = false;
         if (!valid[r]) break;
         if constexpr (!kDesc) {
@@ -208,7 +215,6 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
           // valid -- so that no control-flow join sits in front of the record's wait (s_waitcnt vmcnt(3), not vmcnt(0)).
           if (!project_to_pixel(c, kf, mk3(st(r, 0), st(r, 1), st(r, 2)), &p)) break;
           const PixelRecord rec = load_record(c, kf, p);
-          f2 color_pxy, t1, t2;
           has_desc = depth_to_color_pxy_in_bounds(c, p.pxy, &color_pxy);
           project_tangent_points(mk3(st(r, 6), st(r, 7), st(r, 8)), mk3(st(r, 9), st(r, 10), st(r, 11)), kf.frame_T_global, c, &t1, &t2);
           ds = descriptor_samples_issue(kf, c, color_pxy, t1, t2);
@@ -226,7 +232,8 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
         if (kDesc) {                                            // BS/kernel_opt_pose.cu:320-382
           if (has_desc) {
             float r1, rr2, gx1, gy1, gx2, gy2;
-            descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
+            descriptor_samples_finish(kf, c, ds, desc1[r], desc2[r], [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2;
+            }, &r1, &rr2, &gx1, &gy1, &gx2, &gy2);
             gx1 *= c.cfx; gx2 *= c.cfx;
             gy1 *= c.cfy; gy2 *= c.cfy;
             descriptor_pose_jacobian(gx1, gy1, p.local, J);
