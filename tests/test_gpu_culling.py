@@ -225,3 +225,40 @@ def test_pcg_intrinsics_lifecycle_and_activation_with_and_without_culling(use_de
         assert np.array_equal(a_, b_), i
     assert out[1][0].sum() > 0.9 * S                                    # activation did its job
     assert np.isfinite(out[1][1].view(np.float32)).all()
+
+
+def test_mixed_keyframe_activations_with_and_without_culling():
+    """Keyframe activation states enter the per-lane decision next to the frustum test (activation pass: ACTIVE only; geometry
+    passes: not INACTIVE; pose loop: INACTIVE keyframes are not optimised): the same outputs with culling on and off."""
+    import torch
+    K = 72
+    dev = synthetic.TorchStack(K, "cuda:0", kind="trajectory", border_valid=True)
+    run = Runner(dev, True)
+    L, h = run.L, run.ctx.handle
+    S = dev.surfels_size
+    kfs = run.views()
+    for k in range(K):
+        kfs[k].activation = abi.KF_INACTIVE if k % 3 == 1 else (abi.KF_COVISIBLE_ACTIVE if k % 5 == 2 else abi.KF_ACTIVE)
+    rng = np.random.default_rng(3)
+    inits = (abi.SE3f * K)()
+    for k in range(K):
+        inits[k] = dev.stack.pose(k, np.concatenate([rng.choice([-1, 1], 3) * 0.004, rng.choice([-1, 1], 3) * 0.001]))[0]
+    start = dev.surfels.clone()
+    out = {}
+    for on in (1, 0):
+        run.culling(on)
+        dev.surfels.copy_(start)
+        dev.active.fill_(0)
+        dp, sb, ab = dev.depth_params(), dev.buf(dev.surfels), dev.buf(dev.active)
+        badslam_amd.check(L.bslam_update_surfel_activation(h, run.stream, C.byref(run.cam), C.byref(dp), K, kfs, S, C.byref(sb), C.byref(ab)))
+        act = dev.active[0, :S].cpu().numpy().copy()
+        run.geometry(kfs)
+        surf = bits(dev.surfels[:8].cpu().numpy())
+        poses, iters = run.poses(kfs, inits, 3)
+        out[on] = (act, surf, bits(poses), np.array(iters))
+    dev.surfels.copy_(start)
+    for a_, b_ in zip(out[1], out[0]):
+        assert np.array_equal(a_, b_)
+    assert 0 < out[1][0].sum() < S                                     # surfels only seen by inactive / covisible keyframes stay inactive
+    inactive = np.array([k % 3 == 1 for k in range(K)])
+    assert (out[1][3][inactive] == 0).all() and (out[1][3][~inactive] > 0).all()
