@@ -406,10 +406,18 @@ static int choose_kfs_per_block(int tiles, int kf_count) {
   int per_block = (kf_count + chunks - 1) / chunks;
   // Large surfel counts give enough blocks with one chunk, but then every block walks the whole keyframe list and the
   // resident blocks spread over all of it; a cap keeps the blocks in flight (chunk-major order) on a few keyframes.
+  // (Measured flat optimum 12 ... 32 keyframes with one visit bit per keyframe in a 32-bit word: K = 200: -7 %, K = 300 photometric:
+  // -13 % kernel time; with the per-surfel order 32: 15.5 ms, 16: 15.8, 8: 16.2.)  Round 3, 64-bit visit words: where the surfels
+  // alone give enough workgroups (>= 8192 work slots) a chunk of up to 64 keyframes halves the number of (slot, chunk) workgroups
+  // that only start, test and leave on stacks with most pairs out of view, and costs nothing on the dense one -- K = 300
+  // photometric dense 13.38 vs 13.36 ms, trajectory stack 1316 -> 1244 us, survey-range stack 4.59 -> 4.36 ms, K = 1000 geometry-
+  // only 26.1 -> 25.4 ms; with fewer slots the longer chunks leave too few workgroups for an even tail (K = 200, 2500 slots:
+  // 1149 -> 1187 us), so those keep 32.
 #ifndef BSLAM_POSE_MAX_KFS_PER_BLOCK
-#define BSLAM_POSE_MAX_KFS_PER_BLOCK 32   /* measured flat optimum 12 ... 32 (K = 200: -7 %, K = 300 photometric: -13 % kernel time; with the per-surfel order 32: 15.5 ms, 16: 15.8, 8: 16.2, 64: 15.6); 0: no cap */
+#define BSLAM_POSE_MAX_KFS_PER_BLOCK 0   /* 0: 64 with >= 8192 work slots, else 32 */
 #endif
-  if (BSLAM_POSE_MAX_KFS_PER_BLOCK > 0 && per_block > BSLAM_POSE_MAX_KFS_PER_BLOCK) per_block = BSLAM_POSE_MAX_KFS_PER_BLOCK;
+  const int cap = BSLAM_POSE_MAX_KFS_PER_BLOCK > 0 ? BSLAM_POSE_MAX_KFS_PER_BLOCK : (tiles >= 8192 ? 64 : 32);
+  if (per_block > cap) per_block = cap;
   return per_block;
 }
 
@@ -447,11 +455,11 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   if (rc) return rc;
   rc = ctx->coeffs.reserve((size_t)kf_count * kRow * sizeof(float));
   if (rc) return rc;
-  const int per_block = choose_kfs_per_block(tiles, kf_count);   // <= 32: one bit per keyframe of a chunk in a vis word
+  const int per_block = choose_kfs_per_block(tiles, kf_count);   // <= 64: one bit per keyframe of a chunk in a visit word
   const unsigned chunks = (unsigned)((kf_count + per_block - 1) / per_block);
   if (kfs_per_block_out) *kfs_per_block_out = per_block;
-  if ((rc = ctx->vis.reserve((size_t)chunks * sc.slots * sizeof(uint32_t)))) return rc;
-  uint32_t* vis = (uint32_t*)ctx->vis.ptr;
+  if ((rc = ctx->vis.reserve((size_t)chunks * sc.slots * sizeof(VisWord)))) return rc;
+  VisWord* vis = (VisWord*)ctx->vis.ptr;
   dim3 grid(8u * sc.slots_per_xcd * chunks);
   const SurfelRows rows = work->rows;
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
@@ -477,7 +485,7 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a thread's
   // share at most rows / 32 * 256 -- exact in fp32 up to 2^24
   hipLaunchKernelGGL(pose_reduce_rows_kernel, dim3((unsigned)kf_count), dim3(1024), (unsigned)visit_map_bytes(tiles), stream, (const float*)partials, rows_per_kf, kf_count,
-                     (float*)ctx->coeffs.ptr, states, (const uint32_t*)vis, per_block, cull_stats_ptr(ctx));
+                     (float*)ctx->coeffs.ptr, states, (const VisWord*)vis, per_block, cull_stats_ptr(ctx));
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -978,7 +986,7 @@ int bslam_estimate_frame_poses_batched(
         ProfScope prof(ctx, stream, BSLAM_PROF_POSE_REDUCE);
         hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), (unsigned)visit_map_bytes(tiles), stream, (const float*)ctx->partials.ptr,
                            tiles * kPoseRowsPerSlot, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3),
-                           (const uint32_t*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx));
+                           (const VisWord*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx));
       }
       BSLAM_HIP_TRY(hipGetLastError());
     } else {

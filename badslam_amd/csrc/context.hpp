@@ -163,7 +163,7 @@ struct bslam_context {
   bool sorted_key_bounds = false;
   uint64_t sorted_key_perm_serial = 0;   // the permutation the copy was made with
   uint64_t perm_serial = 0;              // counts rebuilds of `perm`
-  bslam::Slab vis;           // uint32[chunks][slots]: keyframes of a chunk a work slot visited in the last pose_accumulate launch
+  bslam::Slab vis;           // uint64[chunks][slots]: keyframes of a chunk (<= 64) a work slot visited in the last pose_accumulate launch
   bool culling = true;       // block-level frustum culling in the pair kernels (bslam_set_culling)
   const void* perm_key_ptr = nullptr;
   uint32_t perm_key_size = 0;

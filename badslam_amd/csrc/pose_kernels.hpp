@@ -106,13 +106,14 @@ constexpr int kRedCols = 8;
 // two groups ahead: the barrier).  A quarter of the row traffic of one row per wave: the row sums of a batched Gauss-Newton
 // iteration at K = 300 go from 428 to about 110 us.
 constexpr int kPoseRowsPerSlot = 1;
+typedef unsigned long long VisWord;   // visit word of a (chunk, work slot): one bit per keyframe of the chunk (<= 64)
 constexpr int kPoseStashGroup = 4;
 // kCost: the robust cost (column kRowCost) is wanted -- only the per-keyframe debug entry point returns it; the batched
 // Gauss-Newton loop never does, and leaves the tukey / huber residual evaluations out.
 template <bool kDepth, bool kDesc, int kPoseR, bool kCost>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
-    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, uint32_t* __restrict__ vis) {
+    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, VisWord* __restrict__ vis) {
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
   // blocks run chunk-major over that XCD's range of surfel slots.
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   const int kf_end = min(kf_count, kf_begin + kfs_per_block);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  // Which keyframes of the chunk (<= 32) this block visits, decided for all of them at once, one keyframe per lane: not
+  // Which keyframes of the chunk (<= 64) this block visits, decided for all of them at once, one keyframe per lane: not
   // converged (late Gauss-Newton iterations: most chunks have nothing left to do) and -- block-level frustum culling -- the
   // bounding box of the slot's surfels reaches into the keyframe's image.  The word goes to vis[chunk][slot]: the row sums
   // (pose_reduce_*_kernel) only read the partial rows of visited (slot, keyframe) pairs, the others are never written.
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     const bool wanted = states == nullptr || (k < kf_end && !states[k].converged);
     todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc, slot, kPoseR, wanted);
   }
-  if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = (uint32_t)todo;
+  if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = todo;
   if (todo == 0) return;   // leaves before touching the surfels
 
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
@@ -326,7 +327,7 @@ __host__ __device__ __forceinline__ size_t visit_map_bytes(int slots) {
   return (size_t)(((slots + kSlotsPerPass - 1) / kSlotsPerPass) * kWordsPerPass) * sizeof(unsigned long long);
 }
 // Returns the number of visiting slots (valid in every thread after the trailing barrier).
-__device__ __forceinline__ uint32_t build_visit_map(const uint32_t* __restrict__ vis, uint32_t bit, int slots, unsigned long long* __restrict__ vmap) {
+__device__ __forceinline__ uint32_t build_visit_map(const VisWord* __restrict__ vis, uint32_t bit, int slots, unsigned long long* __restrict__ vmap) {
   __shared__ uint32_t visiting;
   if (threadIdx.x == 0) visiting = 0;
   __syncthreads();
@@ -334,7 +335,7 @@ __device__ __forceinline__ uint32_t build_visit_map(const uint32_t* __restrict__
   uint32_t mine = 0;
   for (int s0 = 0; s0 < padded; s0 += (int)blockDim.x) {
     const int sl = s0 + (int)threadIdx.x;
-    const bool v = sl < slots && ((vis[sl] >> bit) & 1u);
+    const bool v = sl < slots && ((vis[sl] >> bit) & 1ull);
     const unsigned long long w = __ballot(v);
     if ((threadIdx.x & 63u) == 0 && sl < padded) { vmap[sl >> 6] = w; mine += (uint32_t)__builtin_popcountll(w); }
   }
@@ -370,7 +371,7 @@ __device__ __forceinline__ float column_share_of_rows(const float* __restrict__ 
 // that repeated in-place all-reduces never grow stale values.
 __global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                float* __restrict__ coeffs, const PoseState* __restrict__ states,
-                                                               const uint32_t* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
+                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
   const int k = blockIdx.x;
   if (states != nullptr && states[k].converged) {
     if (threadIdx.x < kRow) coeffs[(size_t)k * kRow + threadIdx.x] = 0.f;
@@ -618,7 +619,7 @@ constexpr int kReduceSolveThreads = 1024;
 __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                                PoseState* __restrict__ states, KfDev* __restrict__ kfs,
                                                                                int* __restrict__ active_count, int* __restrict__ next_active_count,
-                                                                               const uint32_t* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
+                                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
   const int k = blockIdx.x;
   if (k == 0 && threadIdx.x == 0) *next_active_count = 0;   // the next iteration's counter (last read four iterations ago)
   if (states[k].converged) return;   // uniform
