@@ -100,14 +100,23 @@ __device__ __forceinline__ void accumulate_h_b(float raw, float w, const float* 
 // Measured against the transposing butterfly (wave_transpose_sum32, still used by the image-pair kernels) on one box: photometric
 // K = 300 pose kernel 14.90 -> 14.37 ms with 8 columns per round (4: no gain; 16: the tile costs the photometric kernel a
 // block per CU), geometry-only K = 50 / 200: 94.6 -> 90.8 us / 1206 -> 1160 us.
-constexpr int kRedCols = 8;
+#ifndef BSLAM_POSE_REDUCE_COLS_DESC
+#define BSLAM_POSE_REDUCE_COLS_DESC 4
+#endif
+#ifndef BSLAM_POSE_STASH_GROUP_DESC
+#define BSLAM_POSE_STASH_GROUP_DESC 2
+#endif
+// columns per round / stashed keyframes per barrier: 8 / 4 for the geometry-only kernels; the photometric ones, whose 24 KB of
+// per-surfel constants already sit in LDS, take 4 / 2 so that tiles (4 KB) and stash (2 KB) leave FIVE workgroups per CU
+// (30 KB; 32 KB already means four): K = 300 dense 13.47 -> 13.27 ms, trajectory stack 1252 -> 1203 us, survey 4.40 -> 4.28 ms
+constexpr int kRedColsGeo = 8, kRedColsDesc = BSLAM_POSE_REDUCE_COLS_DESC;
 // One partial row per (work slot, keyframe): the four waves' rows meet in an LDS stash, one barrier per kPoseStashGroup visited
 // keyframes (two stashes alternate, so a wave that runs ahead never overwrites rows that are still being added; it cannot get
 // two groups ahead: the barrier).  A quarter of the row traffic of one row per wave: the row sums of a batched Gauss-Newton
 // iteration at K = 300 go from 428 to about 110 us.
 constexpr int kPoseRowsPerSlot = 1;
 typedef unsigned long long VisWord;   // visit word of a (chunk, work slot): one bit per keyframe of the chunk (<= 64)
-constexpr int kPoseStashGroup = 4;
+constexpr int kPoseStashGroupGeo = 4, kPoseStashGroupDesc = BSLAM_POSE_STASH_GROUP_DESC;
 // kCost: the robust cost (column kRowCost) is wanted -- only the per-keyframe debug entry point returns it; the batched
 // Gauss-Newton loop never does, and leaves the tukey / huber residual evaluations out.
 template <bool kDepth, bool kDesc, int kPoseR, bool kCost>
@@ -147,6 +156,8 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   constexpr int kState = 12;
   __shared__ float state[kDesc ? kState * kPoseR * kPoseThreads : 1];
   float desc1[kDesc ? kPoseR : 1], desc2[kDesc ? kPoseR : 1];   // in registers: 24 + 8 + 4 KB of LDS per block leave four blocks per CU
+  constexpr int kRedCols = kDesc ? kRedColsDesc : kRedColsGeo;
+  constexpr int kPoseStashGroup = kDesc ? kPoseStashGroupDesc : kPoseStashGroupGeo;
   __shared__ float row_stash[2][kPoseStashGroup][kPoseThreads / 64][kRow];
   __shared__ int stash_kf[2][kPoseStashGroup];
   int stashed = 0, stash_buf = 0;   // uniform
