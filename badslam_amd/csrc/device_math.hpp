@@ -14,6 +14,23 @@
 
 #include "../../include/badslam_hip.h"
 
+// A/B switches of the round (tools/variants.py builds one library per setting)
+#ifndef BSLAM_HOIST_T
+#define BSLAM_HOIST_T 1
+#endif
+#ifndef BSLAM_HOIST_C
+#define BSLAM_HOIST_C 1
+#endif
+#ifndef BSLAM_HOIST_GEO
+#define BSLAM_HOIST_GEO 0
+#endif
+#ifndef BSLAM_PCG_CONTRACT
+#define BSLAM_PCG_CONTRACT 1
+#endif
+#ifndef BSLAM_REDUCE_2STAGE
+#define BSLAM_REDUCE_2STAGE 1
+#endif
+
 namespace bslam {
 
 struct f3 { float x, y, z; };
@@ -671,6 +688,23 @@ __device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, fl
 #define BSLAM_ZERO(x) ((x) = 0.f)
 #endif
 
+// A wave-uniform value copied into a vector register by an opaque instruction.  A VOP3 instruction reads at most ONE scalar
+// operand on gfx950, so fma(s_a, v, s_b) costs a v_mov of s_b in front of every such fma -- the compiler re-materialises the copy
+// at each use rather than keep it live; the opaque copy is made once and stays.
+#define BSLAM_TO_VGPR(x) do { float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); (x) = v_; } while (0)
+#if BSLAM_HOIST_T
+#define BSLAM_HOIST_KF_TRANSLATION(kf) do { BSLAM_TO_VGPR((kf).frame_T_global.m[3]); BSLAM_TO_VGPR((kf).frame_T_global.m[7]); BSLAM_TO_VGPR((kf).frame_T_global.m[11]); } while (0)
+#else
+#define BSLAM_HOIST_KF_TRANSLATION(kf) do { } while (0)
+#endif
+#if BSLAM_HOIST_C == 1
+#define BSLAM_HOIST_CAM_CENTRES(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); BSLAM_TO_VGPR((c).ccx); BSLAM_TO_VGPR((c).ccy); } while (0)
+#elif BSLAM_HOIST_C == 2
+#define BSLAM_HOIST_CAM_CENTRES(c) do { BSLAM_TO_VGPR((c).ccx); BSLAM_TO_VGPR((c).ccy); } while (0)
+#else
+#define BSLAM_HOIST_CAM_CENTRES(c) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // XCD-aware work schedule.  Surfels are handled in granules of 256 consecutive columns.  The
 // host sorts the granules along a Morton curve of their centroids (`order`), and the sorted
@@ -910,6 +944,73 @@ __device__ __forceinline__ float wave_column_sums_lds(const float (&v)[N], float
     mine = take ? t : mine;
   }
   return mine;
+}
+
+// Two-stage form of the same sums: a round stops after the in-register adds (each lane then holds the sum of kCols lanes' values of
+// one column), and the partial sums of FOUR rounds go through the tile a second time -- one more ds_read_b128 and three adds --
+// before the DPP steps, which are then needed once per four rounds and only among 16 / kCols lanes.  kCols = 4: 3 adds per round +
+// (3 adds + 2 DPP adds) per four rounds = 31 VALU instructions for 27 columns instead of 56; kCols = 8: 7 per round + (3 + 1) =
+// 32 instead of 44.  Afterwards `*col` is the column whose wave total the lane returns (every column of [0, 32) has a lane with
+// `*writer` set; columns >= kLive return 0).  Same tile, same in-order LDS execution argument as above: no barrier.
+template <int kLive, int kCols, int N>
+__device__ __forceinline__ float wave_column_sums_lds2(const float (&v)[N], float* __restrict__ tile, int* col, bool* writer) {
+  static_assert(kLive >= 1 && kLive <= N && N <= 32, "at most 32 columns");
+  static_assert(kCols == 4 || kCols == 8, "4 or 8 columns per round");
+  constexpr uint32_t L = 64 / kCols;
+  constexpr int kRounds = (kLive + kCols - 1) / kCols;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t g = lane / L, i = lane % L;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float total[(kRounds + 3) / 4];
+#pragma unroll
+  for (int b = 0; b < (kRounds + 3) / 4; ++b) {
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * b + rr;
+      if (r >= kRounds) break;
+#pragma unroll
+      for (int q = 0; q < kCols; ++q)
+        if (kCols * r + q < kLive) tile[q * 64 + lane] = v[kCols * r + q];
+      __builtin_amdgcn_wave_barrier();
+      const v4f x = *reinterpret_cast<const v4f*>(tile + g * 64 + i * kCols);
+      p[rr] = (x.x + x.y) + (x.z + x.w);
+      if constexpr (kCols == 8) {
+        const v4f y = *reinterpret_cast<const v4f*>(tile + g * 64 + i * kCols + 4);
+        p[rr] = p[rr] + ((y.x + y.y) + (y.z + y.w));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // second pass: p[rr] of lane (g, i) is the partial sum of column kCols (4 b + rr) + g over the lanes kCols i .. kCols i + kCols - 1
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      if (4 * b + rr < kRounds) tile[rr * 64 + lane] = p[rr];
+    __builtin_amdgcn_wave_barrier();
+    // lane (rr2, g2, i2) = (lane / 16, (lane % 16) / (16 / kCols), lane % (16 / kCols)) adds four neighbouring partial sums of column
+    // kCols (4 b + rr2) + g2; 16 / kCols lanes share a column
+    const v4f z = *reinterpret_cast<const v4f*>(tile + (lane / 16u) * 64 + ((lane % 16u) / (16u / kCols)) * L + 4 * (lane % (16u / kCols)));
+    __builtin_amdgcn_wave_barrier();
+    float t = (z.x + z.y) + (z.z + z.w);
+    t = dpp_add_xor1(t, t);
+    if constexpr (kCols == 4) t = dpp_add_xor2(t, t);
+    total[b] = t;
+  }
+  // column of batch b in this lane: 4 kCols b + kCols (lane / 16) + (lane % 16) / (16 / kCols) = 4 kCols b + lane / (16 / kCols) ... (kCols = 4: lane / 4; 8: lane / 2)
+  constexpr uint32_t kShare = 16u / kCols;   // lanes per column after the second pass
+  const uint32_t base = lane / kShare;       // 0 .. 4 kCols - 1
+  if constexpr ((kRounds + 3) / 4 == 1) {
+    *col = (int)base;
+    *writer = (lane % kShare) == 0 && base < 32u;
+    return ((int)base < kLive) ? total[0] : 0.f;
+  } else {
+    static_assert((kRounds + 3) / 4 == 2 && kShare >= 2, "two batches need two lanes per column");
+    const bool second = (lane % kShare) == 1;
+    const int c = (int)base + (second ? 4 * kCols : 0);
+    *col = c;
+    *writer = (lane % kShare) < 2 && c < 32;
+    const float t = second ? total[1] : total[0];
+    return (c < kLive) ? t : 0.f;
+  }
 }
 
 // Generic form for N = 8 or 16 values: N - 1 exchanges down to one value per lane, then log2(64 / N)

@@ -510,8 +510,9 @@ __global__ __launch_bounds__(256) void geometry_chunk_kernel(CamConsts c, const 
 #define BSLAM_GEOM_DESC_WAVES 4
 #endif
 template <int R, int kPass, bool kDepth>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_DESC_WAVES))) void geometry_desc_chunk_kernel(CamConsts c, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_DESC_WAVES))) void geometry_desc_chunk_kernel(CamConsts c_in, const KfDev* __restrict__ kfs, int k_begin, int k_end, int first_chunk, int last_chunk,
                                                                  Schedule sc, uint32_t first_i, SurfelRowsRW s, float* __restrict__ acc, uint32_t acc_pitch) {
+  CamConsts c = c_in;
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x + (first_i << 3), &slot)) return;
   constexpr int kAcc = kPass == 0 ? 4 : 8;
@@ -535,8 +536,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
 #pragma unroll
     for (int q = 0; q < kAcc; ++q) a[r][q] = (!first_chunk && on[r]) ? acc[(size_t)q * acc_pitch + j] : 0.f;
   }
+  if constexpr (kPass == 1) BSLAM_HOIST_CAM_CENTRES(c);
   BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end, R) {
-    const KfDev kf = kfs[k];
+    KfDev kf = kfs[k];
+    if constexpr (kPass == 1) BSLAM_HOIST_KF_TRANSLATION(kf);
     const float* Rm = kf.global_R_frame;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -565,6 +568,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         a[r][3] += 1.f;
       } else {
         // accumulators: [0] H00, [1] H01, [2] H02, [3] H11, [4] H22, [5] b0, [6] b1, [7] b2   (H12 is never accumulated: quirk Q2)
+#if BSLAM_PCG_CONTRACT
+#pragma clang fp contract(fast)
+#endif
         const f3 rn = p.n_local;
         if (kDepth) {
           const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);

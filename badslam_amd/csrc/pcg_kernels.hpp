@@ -55,10 +55,18 @@ struct PcgRowStash {
 // iteration 340 -> 321 ms; K = 50 geometry-only 210 -> 187 us and 270 -> 195 us).
 template <int kLive>
 __device__ __forceinline__ void pcg_stash_wave_sums(PcgRowStash& st, int buf, int at, int k, const float (&pose)[kPcgPoseRow]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6;
+#if BSLAM_REDUCE_2STAGE
+  int col;
+  bool writer;
+  const float total = wave_column_sums_lds2<kLive, 4>(pose, st.tile[wave], &col, &writer);   // column lane / 4 in every fourth lane
+  if (writer && col < kPcgPoseRow) st.v[buf][at][wave][col] = total;
+#else
+  const int lane = threadIdx.x & 63;
   const float total = wave_column_sums_lds<kLive, 4>(pose, st.tile[wave]);
   const int col = 4 * (lane & 15) + (lane >> 4);   // lane (g, i) = (lane / 16, lane % 16) holds column 4 i + g
   if ((lane & 15) < kPcgPoseRow / 4) st.v[buf][at][wave][col] = total;
+#endif
   if (threadIdx.x == 0) st.kf[buf][at] = k;
 }
 // Adds up and stores the `n` stashed keyframes of buffer `buf` (all threads call; contains the group's one barrier).
@@ -179,8 +187,9 @@ __device__ __forceinline__ DescTerms descriptor_terms_finish(const CamConsts& c,
 // ---------------------------------------------------------------------------------------------
 template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
+    CamConsts c_in, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  CamConsts c = c_in;
   constexpr int R = pcg_surfels_per_thread(kDesc, kIntr);
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
 #pragma unroll
   for (int i = 0; i < kPcgGlobRow; ++i) glob[i] = 0.f;
 
+  if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
   int stashed = 0;   // keyframes in the current stash (uniform)
   int buf = 0;
   for (int k0 = 0; k0 < kf_count; k0 += 64) {
@@ -222,7 +232,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   if (P.optimize_poses && sc.bounds != nullptr) pcg_zero_rows(todo, k0, kf_count, partial_pose, sc.slots, tile);
   for (; todo != 0; todo &= todo - 1) {
     const int k = k0 + __builtin_ctzll(todo);
-    const KfDev kf = kfs[k];
+    KfDev kf = kfs[k];
+    if constexpr (kDesc) BSLAM_HOIST_KF_TRANSLATION(kf);
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pose[kPcgPoseRow];
@@ -249,6 +260,9 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
+#if BSLAM_PCG_CONTRACT
+#pragma clang fp contract(fast)   // past the association test nothing feeds an integer output: products with p and the sums fuse (as nvcc's default does)
+#endif
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = depth_residual(inv_stddev, rn, lu, p.local);
@@ -287,6 +301,9 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         }
       }
       if (kDesc) {                                               // :330-511
+#if BSLAM_PCG_CONTRACT
+#pragma clang fp contract(fast)
+#endif
         visible = visible && has_desc;
         if (!visible) continue;
         const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });
@@ -435,8 +452,9 @@ __global__ __launch_bounds__(kPcgGlobReduceThreads) void pcg_glob_reduce_kernel(
 
 template <bool kDepth, bool kDesc, bool kIntr>
 __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDesc ? BSLAM_PCG_STEP1_WAVES_DESC : 4))) void pcg_step1_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
+    CamConsts c_in, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, SurfelRows s, PcgParams P,
     float* __restrict__ partial_pose, float* __restrict__ partial_glob) {
+  CamConsts c = c_in;
   constexpr int R = pcg_surfels_per_thread(kDesc, kIntr);
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x, &slot)) return;
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (kIntr && P.optimize_depth_intr) for (int j = 0; j < 5; ++j) pdi[j] = P.p[P.depth_intr_start + j];
   if (kIntr && P.optimize_color_intr) for (int j = 0; j < 4; ++j) pci[j] = P.p[P.color_intr_start + j];
 
+  if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
   int stashed = 0;   // keyframes in the current stash (uniform)
   int buf = 0;
   for (int k0 = 0; k0 < kf_count; k0 += 64) {
@@ -487,7 +506,8 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (P.optimize_poses && sc.bounds != nullptr) pcg_zero_rows(todo, k0, kf_count, partial_pose, sc.slots, tile);
   for (; todo != 0; todo &= todo - 1) {
     const int k = k0 + __builtin_ctzll(todo);
-    const KfDev kf = kfs[k];
+    KfDev kf = kfs[k];
+    if constexpr (kDesc) BSLAM_HOIST_KF_TRANSLATION(kf);
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pp[6] = {0, 0, 0, 0, 0, 0};
@@ -519,6 +539,9 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
+#if BSLAM_PCG_CONTRACT
+#pragma clang fp contract(fast)   // past the association test nothing feeds an integer output: products with p and the sums fuse (as nvcc's default does)
+#endif
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = depth_residual(inv_stddev, rn, lu, p.local);
@@ -559,6 +582,9 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         }
       }
       if (kDesc) {
+#if BSLAM_PCG_CONTRACT
+#pragma clang fp contract(fast)
+#endif
         visible = visible && has_desc;
         if (!visible) continue;
         const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });

@@ -121,8 +121,9 @@ constexpr int kPoseStashGroupGeo = 4, kPoseStashGroupDesc = BSLAM_POSE_STASH_GRO
 // Gauss-Newton loop never does, and leaves the tukey / huber residual evaluations out.
 template <bool kDepth, bool kDesc, int kPoseR, bool kCost>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
-    CamConsts c, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
+    CamConsts c_in, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
     SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, VisWord* __restrict__ vis) {
+  CamConsts c = c_in;
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
   // blocks run chunk-major over that XCD's range of surfel slots.
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -191,10 +192,12 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     }
   }
 
+  if constexpr (kDesc || (BSLAM_HOIST_GEO && kPoseR > 4)) BSLAM_HOIST_CAM_CENTRES(c);
   while (todo != 0) {   // uniform
     const int k = kf_begin + __builtin_ctzll(todo);
     todo &= todo - 1;
-    const KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
+    KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
+    if constexpr (kDesc || (BSLAM_HOIST_GEO && kPoseR > 4)) BSLAM_HOIST_KF_TRANSLATION(kf);
     float acc[kRow];
     // Every live accumulator is zeroed by its own opaque instruction.  Written as acc[i] = 0.f the optimiser knows all of
     // them to be one value: it folds the first surfel's fma(wj, J, 0) into a multiply and then has to materialise the zeros a
@@ -264,11 +267,19 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     const bool any = count != 0;   // uniform
     float total = 0.f;
     constexpr int kLive = kCost ? kRowCost + 1 : kRowCost;   // 21 H, 6 b (, cost); the count column is filled in below
+#if BSLAM_REDUCE_2STAGE
+    int my_col = (int)(lane / (16 / kRedCols)) + ((kRedCols == 4 && (lane & 1)) ? 16 : 0);
+    bool writer = (lane % (16 / kRedCols)) < (kRedCols == 4 ? 2 : 1);
+    if (any) total = wave_column_sums_lds2<kLive, kRedCols>(acc, red_tile[wave], &my_col, &writer);
+    if (my_col == kRowCount) total = (float)count;   // <= 64 * kPoseR: exact
+    if (writer) row_stash[stash_buf][stashed][wave][my_col] = total;
+#else
     if (any) total = wave_column_sums_lds<kLive, kRedCols>(acc, red_tile[wave]);
     constexpr int kRedLanes = 64 / kRedCols;   // lanes per column: lane (g, i) = (lane / kRedLanes, lane % kRedLanes) holds column kRedCols i + g
     const int my_col = kRedCols * (lane % kRedLanes) + lane / kRedLanes;
     if (my_col == kRowCount) total = (float)count;   // <= 64 * kPoseR: exact
     if ((lane % kRedLanes) < kRow / kRedCols) row_stash[stash_buf][stashed][wave][my_col] = total;
+#endif
     if (threadIdx.x == 0) stash_kf[stash_buf][stashed] = k;
     if (++stashed == kPoseStashGroup) { flush_rows(stashed); stashed = 0; stash_buf ^= 1; }
   }
