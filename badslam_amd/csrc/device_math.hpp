@@ -14,23 +14,9 @@
 
 #include "../../include/badslam_hip.h"
 
-// A/B switches of the round (tools/variants.py builds one library per setting)
-#ifndef BSLAM_HOIST_T
-#define BSLAM_HOIST_T 1
+#ifndef BSLAM_TRY_GEOM_HOIST
+#define BSLAM_TRY_GEOM_HOIST 0
 #endif
-#ifndef BSLAM_HOIST_C
-#define BSLAM_HOIST_C 1
-#endif
-#ifndef BSLAM_HOIST_GEO
-#define BSLAM_HOIST_GEO 0
-#endif
-#ifndef BSLAM_PCG_CONTRACT
-#define BSLAM_PCG_CONTRACT 1
-#endif
-#ifndef BSLAM_REDUCE_2STAGE
-#define BSLAM_REDUCE_2STAGE 1
-#endif
-
 namespace bslam {
 
 struct f3 { float x, y, z; };
@@ -265,6 +251,13 @@ __device__ __forceinline__ T gload(const T* p) {
   return *(const __attribute__((address_space(1))) T*)(p);
 }
 
+// The same at a 32-bit BYTE offset from a wave-uniform base: the load takes the base from an SGPR pair and the offset from one
+// VGPR (global_load ... v_off, s[base:base+1]) -- no 64-bit address arithmetic per lane, one VGPR per address instead of two.
+template <class T>
+__device__ __forceinline__ T gload_at(const T* base, uint32_t byte_offset) {
+  return *(const __attribute__((address_space(1))) T*)((const __attribute__((address_space(1))) char*)base + byte_offset);
+}
+
 __device__ __forceinline__ uint2 gload_u2(const uint2* p) {   // one 8-byte load
   const unsigned long long v = gload((const unsigned long long*)p);
   return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
@@ -288,8 +281,13 @@ __device__ __forceinline__ LumaQuad unpack_quad(uint32_t q) {
 
 // i in [-1, w-1], j in [-1, h-1]
 __device__ __forceinline__ uint32_t quad_at(const KfDev& kf, const CamConsts& c, int i, int j) {
-  // offset inside one keyframe's table: < 2^24, 32-bit arithmetic (v_mad_u32_u24) on top of the uniform base
-  return gload(kf.quads + (__umul24((uint32_t)(j + 1), (uint32_t)(c.color_width + 1)) + (uint32_t)(i + 1)));
+  // byte offset inside one keyframe's table: < 2^26, 32-bit arithmetic (v_mul_u32_u24, v_lshl_add_u32) on top of the uniform base
+  // (j + 1) * pitch + (i + 1) * 4 as  j * pitch + (4 i + (pitch + 4)):  v_lshl_add_u32 + v_mad_i32_i24 (j and i may be -1; the sum is not)
+  const int pitch = 4 * (c.color_width + 1);
+  const uint32_t t = ((uint32_t)i << 2) + (uint32_t)(pitch + 4);
+  uint32_t off;   // written out: the compiler splits the constant off again and spends a third instruction on it
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(off) : "v"(j), "s"(pitch), "v"(t));
+  return gload_at(kf.quads, off);
 }
 
 // Bilinear footprint of a sample at pixel-corner coordinates (x, y): base texel (clamped to the quad
@@ -441,7 +439,11 @@ __device__ __forceinline__ void descriptor_samples_finish(const KfDev& kf, const
     val[k] = bilinear_bytes(t, d.f[k].a, d.f[k].b);
     bilinear_gradient_bytes(t, d.f[k].ua, d.f[k].ub, &gx[k], &gy[k]);
   }
-  if (!(d.f[0].interior & d.f[1].interior & d.f[2].interior)) {   // some sample's 2x2 footprint touches the image border
+  // some sample's 2x2 footprint touches the image border: a base texel outside [0, w - 2] x [0, h - 2] (-1 is the largest unsigned
+  // value), decided on the maxima of the three base texels (two v_max3_u32 and two compares instead of six compares)
+  const uint32_t max_i = max(max((uint32_t)d.f[0].i, (uint32_t)d.f[1].i), (uint32_t)d.f[2].i);
+  const uint32_t max_j = max(max((uint32_t)d.f[0].j, (uint32_t)d.f[1].j), (uint32_t)d.f[2].j);
+  if ((max_i >= (uint32_t)(c.color_width - 1)) | (max_j >= (uint32_t)(c.color_height - 1))) {
     f2 pts[3];
     sample_points(pts);
 #pragma unroll
@@ -549,8 +551,9 @@ __device__ __forceinline__ bool project_to_pixel(const CamConsts& c, const KfDev
 // Stage 2: the pixel's derived record.  The offset inside one keyframe's table fits 24 bits (v_mad_u32_u24, full rate) and is
 // added to the uniform base as a 32-bit offset (global_load with an SGPR base): no 64-bit vector arithmetic per gather.
 __device__ __forceinline__ PixelRecord load_record(const CamConsts& c, const KfDev& kf, const Proj& r) {
-  const uint32_t idx = __umul24((uint32_t)r.py, (uint32_t)c.width) + (uint32_t)r.px;
-  return gload_record(kf.records + idx);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = gload_at((const v4f*)kf.records, __umul24((uint32_t)r.py, 16u * (uint32_t)c.width) + ((uint32_t)r.px << 4));   // < 2^28
+  return PixelRecord{v.x, v.y, v.z, v.w};
 }
 // raw u16 depth of the associated pixel (only the depth-intrinsics Jacobians need it)
 __device__ __forceinline__ uint32_t raw_depth_of(const KfDev& kf, const Proj& r) {
@@ -595,6 +598,7 @@ __device__ __forceinline__ bool project_and_associate(const CamConsts& c, const 
 __device__ __forceinline__ float depth_residual(float inv_stddev, f3 n_local, f3 lu, f3 ls) { return inv_stddev * dot(n_local, sub3(lu, ls)); }
 // ... and its Jacobian wrt. the pose delta (BS/kernel_opt_pose.cu:45-94)
 __device__ __forceinline__ void depth_pose_jacobian(float inv_stddev, f3 n_local, f3 lu, float* J) {
+#pragma clang fp contract(fast)
   J[0] = inv_stddev * n_local.x;
   J[1] = inv_stddev * n_local.y;
   J[2] = inv_stddev * n_local.z;
@@ -630,21 +634,36 @@ __device__ __forceinline__ float depth_position_jacobian(float inv_stddev) { ret
 // colour camera's fx, fy; ls = surfel position in the frame.  kExact: correctly rounded reciprocal (odometry, as the oracle).
 template <bool kExact = false>
 __device__ __forceinline__ void descriptor_pose_jacobian(float gx, float gy, f3 ls, float* J) {
-  const float inv_ls_z = kExact ? 1.f / ls.z : rrcp(ls.z);
-  const float ls_z_sq = ls.z * ls.z;
-  const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
-  J[0] = -gx * inv_ls_z;
-  J[1] = -gy * inv_ls_z;
-  J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
-  const float ls_x_y = ls.x * ls.y;
-  J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
-  J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
-  J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+  if constexpr (kExact) {
+    const float inv_ls_z = 1.f / ls.z;
+    const float ls_z_sq = ls.z * ls.z;
+    const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
+    J[0] = -gx * inv_ls_z;
+    J[1] = -gy * inv_ls_z;
+    J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
+    const float ls_x_y = ls.x * ls.y;
+    J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
+    J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
+    J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+  } else {
+#pragma clang fp contract(fast)   // the BA kernels' form: sums of products fuse (6 instructions less per residual), as under nvcc's default
+    const float inv_ls_z = rrcp(ls.z);
+    const float ls_z_sq = ls.z * ls.z;
+    const float inv_ls_z_sq = inv_ls_z * inv_ls_z;
+    J[0] = -gx * inv_ls_z;
+    J[1] = -gy * inv_ls_z;
+    J[2] = (ls.x * gx + ls.y * gy) * inv_ls_z_sq;
+    const float ls_x_y = ls.x * ls.y;
+    J[3] = ((ls.y * ls.y + ls_z_sq) * gy + ls_x_y * gx) * inv_ls_z_sq;
+    J[4] = -((ls.x * ls.x + ls_z_sq) * gx + ls_x_y * gy) * inv_ls_z_sq;
+    J[5] = -(ls.x * gy - ls.y * gx) * inv_ls_z;
+  }
 }
 // Descriptor residual wrt. a surfel move along its normal (BS/kernel_opt_geometry.cu:175-189, BS/kernel_pcg.cu:364-372):
 // rn = normal in the frame, ls = position in the frame; the gradient (gx, gy) is multiplied by (fx, fy) here (the PCG kernels
 // pass gradients that already carry the focal lengths and fx = fy = 1).
 __device__ __forceinline__ float descriptor_position_jacobian(float gx, float gy, float fx, float fy, f3 rn, f3 ls) {
+  // (not contracted: rn.x * ls.z - rn.z * ls.x cancels, and this single number is held to the CPU checker's at 2e-6)
   const float term1 = -fx * (rn.x * ls.z - rn.z * ls.x);
   const float term2 = -fy * (rn.y * ls.z - rn.z * ls.y);
   const float term3 = rrcp(ls.z * ls.z);
@@ -692,18 +711,9 @@ __device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, fl
 // operand on gfx950, so fma(s_a, v, s_b) costs a v_mov of s_b in front of every such fma -- the compiler re-materialises the copy
 // at each use rather than keep it live; the opaque copy is made once and stays.
 #define BSLAM_TO_VGPR(x) do { float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); (x) = v_; } while (0)
-#if BSLAM_HOIST_T
 #define BSLAM_HOIST_KF_TRANSLATION(kf) do { BSLAM_TO_VGPR((kf).frame_T_global.m[3]); BSLAM_TO_VGPR((kf).frame_T_global.m[7]); BSLAM_TO_VGPR((kf).frame_T_global.m[11]); } while (0)
-#else
-#define BSLAM_HOIST_KF_TRANSLATION(kf) do { } while (0)
-#endif
-#if BSLAM_HOIST_C == 1
 #define BSLAM_HOIST_CAM_CENTRES(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); BSLAM_TO_VGPR((c).ccx); BSLAM_TO_VGPR((c).ccy); } while (0)
-#elif BSLAM_HOIST_C == 2
-#define BSLAM_HOIST_CAM_CENTRES(c) do { BSLAM_TO_VGPR((c).ccx); BSLAM_TO_VGPR((c).ccy); } while (0)
-#else
-#define BSLAM_HOIST_CAM_CENTRES(c) do { } while (0)
-#endif
+#define BSLAM_HOIST_DEPTH_CAM_CENTRE(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); } while (0)   // kernels that never sample the colour image
 
 // ---------------------------------------------------------------------------------------------
 // XCD-aware work schedule.  Surfels are handled in granules of 256 consecutive columns.  The
@@ -904,66 +914,42 @@ __device__ __forceinline__ float wave_transpose_sum32(float (&v)[32]) {
   return dpp_add_xor1(v[0], v[0]);
 }
 
-// The same sums through LDS: the wave writes kCols columns at a time into a [kCols][64] tile (ds_write_b32 per column,
-// conflict-free), every lane reads back kCols neighbouring lanes' values of ONE column (ds_read_b128s: with L = 64 / kCols lanes
-// per column, lane (g, i) = (lane / L, lane % L) reads entries kCols i .. kCols i + kCols - 1 of column g), adds them and finishes
-// with log2(L) DPP adds among the L lanes of its column.  For kCols = 4 that is about 15 instructions per 4 columns, of which 8
-// VALU, instead of ~20 (16 VALU) for the butterfly's selects, ds_bpermutes and adds; the wave's own LDS operations execute in
-// order, so no barrier is needed and the tile is private to the wave.  Columns [0, kLive) are summed; afterwards lane (g, i)
-// with i < ceil(kLive / kCols) holds the wave total of column kCols i + g (0 for a column >= kLive).  Fixed order: deterministic.
+// The same sums through LDS, in two stages.  Stage 1, kCols columns per round: the wave writes them into a [kCols][64] tile
+// (ds_write_b32 per column, conflict-free) and every lane reads back kCols neighbouring lanes' values of ONE column (ds_read_b128s:
+// with L = 64 / kCols lanes per column, lane (g, i) = (lane / L, lane % L) reads entries kCols i .. kCols i + kCols - 1 of column
+// g) and adds them.  Stage 2, once per FOUR rounds: the four partial sums of a lane go through the tile a second time -- one more
+// ds_read_b128 and three adds -- and only then come the DPP adds, among the 16 / kCols lanes that are left per column.
+// kCols = 4: 3 adds per round + (3 adds + 2 DPP adds) per four rounds = 31 VALU instructions for 27 columns (round 3's first
+// form finished every round with log2(L) DPP adds and a select: 56; the transposing butterfly before it: ~190); kCols = 8:
+// 7 per round + (3 + 1) = 32.  The wave's own LDS operations execute in order, so no barrier is needed and the tile is private to
+// the wave.  Afterwards every lane returns the wave total of the column wave_column_sums_owner names (0 for a column >= kLive).  Fixed order:
+// deterministic.
+// Where the totals end up: lane -> (column it holds, whether it is the lane that stores that column).  With one batch of four
+// rounds (<= 4 kCols columns) 16 / kCols lanes share a column; with two batches the first lane of a group holds the column of
+// the first batch and the second lane that of the second.
+template <int kLive, int kCols>
+__device__ __forceinline__ void wave_column_sums_owner(int* col, bool* writer) {
+  constexpr int kBatches = ((kLive + kCols - 1) / kCols + 3) / 4;
+  constexpr uint32_t kShare = 16u / kCols;   // lanes per column after the second stage
+  static_assert(kBatches == 1 || (kBatches == 2 && kShare >= 2), "two batches need two lanes per column");
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t sub = lane % kShare;
+  *col = (int)(lane / kShare) + ((kBatches == 2 && sub == 1) ? 4 * kCols : 0);
+  *writer = sub < (uint32_t)kBatches && *col < 32;
+}
 template <int kLive, int kCols, int N>
 __device__ __forceinline__ float wave_column_sums_lds(const float (&v)[N], float* __restrict__ tile) {
-  static_assert(kLive >= 1 && kLive <= N && N <= 32, "at most 32 columns");
-  static_assert(kCols == 4 || kCols == 8 || kCols == 16, "4, 8 or 16 columns per round");
-  constexpr uint32_t L = 64 / kCols;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t g = lane / L, i = lane % L;
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  float mine = 0.f;
-#pragma unroll
-  for (int r = 0; r < (kLive + kCols - 1) / kCols; ++r) {
-#pragma unroll
-    for (int q = 0; q < kCols; ++q)
-      if (kCols * r + q < kLive) tile[q * 64 + lane] = v[kCols * r + q];
-    __builtin_amdgcn_wave_barrier();
-    float part[kCols / 4];
-#pragma unroll
-    for (int q = 0; q < kCols / 4; ++q) {
-      const v4f x = *reinterpret_cast<const v4f*>(tile + g * 64 + i * kCols + 4 * q);
-      part[q] = (x.x + x.y) + (x.z + x.w);
-    }
-    __builtin_amdgcn_wave_barrier();
-    float t = part[0];
-    if constexpr (kCols == 8) t = part[0] + part[1];
-    if constexpr (kCols == 16) t = (part[0] + part[1]) + (part[2] + part[3]);
-    t = dpp_add_xor1(t, t);
-    t = dpp_add_xor2(t, t);
-    if constexpr (L >= 8) t = dpp_add_half_mirror(t, t);
-    if constexpr (L >= 16) t = dpp_add_ror8(t, t);
-    const bool take = (i == (uint32_t)r) && (kCols * r + kCols - 1 < kLive || (uint32_t)(kCols * r) + g < (uint32_t)kLive);
-    mine = take ? t : mine;
-  }
-  return mine;
-}
-
-// Two-stage form of the same sums: a round stops after the in-register adds (each lane then holds the sum of kCols lanes' values of
-// one column), and the partial sums of FOUR rounds go through the tile a second time -- one more ds_read_b128 and three adds --
-// before the DPP steps, which are then needed once per four rounds and only among 16 / kCols lanes.  kCols = 4: 3 adds per round +
-// (3 adds + 2 DPP adds) per four rounds = 31 VALU instructions for 27 columns instead of 56; kCols = 8: 7 per round + (3 + 1) =
-// 32 instead of 44.  Afterwards `*col` is the column whose wave total the lane returns (every column of [0, 32) has a lane with
-// `*writer` set; columns >= kLive return 0).  Same tile, same in-order LDS execution argument as above: no barrier.
-template <int kLive, int kCols, int N>
-__device__ __forceinline__ float wave_column_sums_lds2(const float (&v)[N], float* __restrict__ tile, int* col, bool* writer) {
   static_assert(kLive >= 1 && kLive <= N && N <= 32, "at most 32 columns");
   static_assert(kCols == 4 || kCols == 8, "4 or 8 columns per round");
   constexpr uint32_t L = 64 / kCols;
   constexpr int kRounds = (kLive + kCols - 1) / kCols;
+  constexpr int kBatches = (kRounds + 3) / 4;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t g = lane / L, i = lane % L;
   typedef float v4f __attribute__((ext_vector_type(4)));
-  float total[(kRounds + 3) / 4];
+  float total[kBatches];
 #pragma unroll
-  for (int b = 0; b < (kRounds + 3) / 4; ++b) {
+  for (int b = 0; b < kBatches; ++b) {
     float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -981,13 +967,14 @@ __device__ __forceinline__ float wave_column_sums_lds2(const float (&v)[N], floa
       }
       __builtin_amdgcn_wave_barrier();
     }
-    // second pass: p[rr] of lane (g, i) is the partial sum of column kCols (4 b + rr) + g over the lanes kCols i .. kCols i + kCols - 1
+    // stage 2: p[rr] of lane (g, i) is the partial sum of column kCols (4 b + rr) + g over the lanes kCols i .. kCols i + kCols - 1
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
       if (4 * b + rr < kRounds) tile[rr * 64 + lane] = p[rr];
     __builtin_amdgcn_wave_barrier();
-    // lane (rr2, g2, i2) = (lane / 16, (lane % 16) / (16 / kCols), lane % (16 / kCols)) adds four neighbouring partial sums of column
-    // kCols (4 b + rr2) + g2; 16 / kCols lanes share a column
+    // lane (rr2, g2, i2) = (lane / 16, (lane % 16) / (16 / kCols), lane % (16 / kCols)) adds four neighbouring partial sums of
+    // column kCols (4 b + rr2) + g2 = 4 kCols b + lane / (16 / kCols); a row of the tile that this batch did not write (a last
+    // batch of fewer than four rounds) only reaches columns >= kLive, which return 0 below
     const v4f z = *reinterpret_cast<const v4f*>(tile + (lane / 16u) * 64 + ((lane % 16u) / (16u / kCols)) * L + 4 * (lane % (16u / kCols)));
     __builtin_amdgcn_wave_barrier();
     float t = (z.x + z.y) + (z.z + z.w);
@@ -995,22 +982,12 @@ __device__ __forceinline__ float wave_column_sums_lds2(const float (&v)[N], floa
     if constexpr (kCols == 4) t = dpp_add_xor2(t, t);
     total[b] = t;
   }
-  // column of batch b in this lane: 4 kCols b + kCols (lane / 16) + (lane % 16) / (16 / kCols) = 4 kCols b + lane / (16 / kCols) ... (kCols = 4: lane / 4; 8: lane / 2)
-  constexpr uint32_t kShare = 16u / kCols;   // lanes per column after the second pass
-  const uint32_t base = lane / kShare;       // 0 .. 4 kCols - 1
-  if constexpr ((kRounds + 3) / 4 == 1) {
-    *col = (int)base;
-    *writer = (lane % kShare) == 0 && base < 32u;
-    return ((int)base < kLive) ? total[0] : 0.f;
-  } else {
-    static_assert((kRounds + 3) / 4 == 2 && kShare >= 2, "two batches need two lanes per column");
-    const bool second = (lane % kShare) == 1;
-    const int c = (int)base + (second ? 4 * kCols : 0);
-    *col = c;
-    *writer = (lane % kShare) < 2 && c < 32;
-    const float t = second ? total[1] : total[0];
-    return (c < kLive) ? t : 0.f;
-  }
+  int col;
+  bool writer;
+  wave_column_sums_owner<kLive, kCols>(&col, &writer);
+  float t = total[0];
+  if constexpr (kBatches == 2) t = (lane % (16u / kCols) == 1) ? total[1] : total[0];
+  return (col < kLive) ? t : 0.f;
 }
 
 // Generic form for N = 8 or 16 values: N - 1 exchanges down to one value per lane, then log2(64 / N)

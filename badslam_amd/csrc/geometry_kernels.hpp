@@ -355,8 +355,9 @@ __global__ __launch_bounds__(256) void residual_probe_kernel(CamConsts c, const 
 // one resident grid at a time to keep the workgroups in lockstep on the keyframe table, which the per-surfel work order made
 // unnecessary (first_i = first slot of every XCD's range handled by a launch is kept for that use).
 template <int R>
-__global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, uint32_t first_i,
+__global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c_in, const KfDev* __restrict__ kfs, int kf_count, Schedule sc, uint32_t first_i,
                                                                SurfelRowsRW s) {
+  CamConsts c = c_in;
   uint32_t slot;
   if (!slot_of_block(sc, blockIdx.x + (first_i << 3), &slot)) return;
   uint32_t idx[R];
@@ -371,12 +372,18 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
   }
+#if BSLAM_TRY_GEOM_HOIST
+  BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
+#endif
   {
     float sx[R], sy[R], sz[R], cnt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
     BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
-      const KfDev kf = kfs[k];
+      KfDev kf = kfs[k];
+#if BSLAM_TRY_GEOM_HOIST
+      BSLAM_HOIST_KF_TRANSLATION(kf);
+#endif
       const float* Rm = kf.global_R_frame;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -403,7 +410,10 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c, con
 #pragma unroll
   for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
   BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
-    const KfDev kf = kfs[k];
+    KfDev kf = kfs[k];
+#if BSLAM_TRY_GEOM_HOIST
+    BSLAM_HOIST_KF_TRANSLATION(kf);
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
@@ -568,9 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
         a[r][3] += 1.f;
       } else {
         // accumulators: [0] H00, [1] H01, [2] H02, [3] H11, [4] H22, [5] b0, [6] b1, [7] b2   (H12 is never accumulated: quirk Q2)
-#if BSLAM_PCG_CONTRACT
-#pragma clang fp contract(fast)
-#endif
+#pragma clang fp contract(fast)   // the position / descriptor sums (compared at 1e-4); the normals pass above feeds packed normals and stays unfused
         const f3 rn = p.n_local;
         if (kDepth) {
           const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);

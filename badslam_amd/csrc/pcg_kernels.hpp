@@ -56,17 +56,11 @@ struct PcgRowStash {
 template <int kLive>
 __device__ __forceinline__ void pcg_stash_wave_sums(PcgRowStash& st, int buf, int at, int k, const float (&pose)[kPcgPoseRow]) {
   const int wave = threadIdx.x >> 6;
-#if BSLAM_REDUCE_2STAGE
   int col;
   bool writer;
-  const float total = wave_column_sums_lds2<kLive, 4>(pose, st.tile[wave], &col, &writer);   // column lane / 4 in every fourth lane
-  if (writer && col < kPcgPoseRow) st.v[buf][at][wave][col] = total;
-#else
-  const int lane = threadIdx.x & 63;
+  wave_column_sums_owner<kLive, 4>(&col, &writer);   // column lane / 4, stored by every fourth lane
   const float total = wave_column_sums_lds<kLive, 4>(pose, st.tile[wave]);
-  const int col = 4 * (lane & 15) + (lane >> 4);   // lane (g, i) = (lane / 16, lane % 16) holds column 4 i + g
-  if ((lane & 15) < kPcgPoseRow / 4) st.v[buf][at][wave][col] = total;
-#endif
+  if (writer && col < kPcgPoseRow) st.v[buf][at][wave][col] = total;
   if (threadIdx.x == 0) st.kf[buf][at] = k;
 }
 // Adds up and stores the `n` stashed keyframes of buffer `buf` (all threads call; contains the group's one barrier).
@@ -260,9 +254,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
-#if BSLAM_PCG_CONTRACT
 #pragma clang fp contract(fast)   // past the association test nothing feeds an integer output: products with p and the sums fuse (as nvcc's default does)
-#endif
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = depth_residual(inv_stddev, rn, lu, p.local);
@@ -301,9 +293,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
         }
       }
       if (kDesc) {                                               // :330-511
-#if BSLAM_PCG_CONTRACT
 #pragma clang fp contract(fast)
-#endif
         visible = visible && has_desc;
         if (!visible) continue;
         const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });
@@ -539,9 +529,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
       bool visible = true;
       const f3 rn = p.n_local;
       if (kDepth) {
-#if BSLAM_PCG_CONTRACT
 #pragma clang fp contract(fast)   // past the association test nothing feeds an integer output: products with p and the sums fuse (as nvcc's default does)
-#endif
         const float inv_stddev = depth_inv_stddev(p.nx, p.ny, p.depth, rn, c.baseline_fx);
         const f3 lu = mk3(p.depth * p.nx, p.depth * p.ny, p.depth);   // unproject(c, p.px, p.py, p.depth)
         const float raw = depth_residual(inv_stddev, rn, lu, p.local);
@@ -582,9 +570,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
         }
       }
       if (kDesc) {
-#if BSLAM_PCG_CONTRACT
 #pragma clang fp contract(fast)
-#endif
         visible = visible && has_desc;
         if (!visible) continue;
         const DescTerms t = descriptor_terms_finish(c, kf, ds, BSLAM_PCG_ST(r, 9), BSLAM_PCG_ST(r, 10), [&](f2 (&pts)[3]) { pts[0] = color_pxy; pts[1] = t1; pts[2] = t2; });

@@ -192,12 +192,13 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     }
   }
 
-  if constexpr (kDesc || (BSLAM_HOIST_GEO && kPoseR > 4)) BSLAM_HOIST_CAM_CENTRES(c);
+  if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
+  else if constexpr (kPoseR > 4) BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
   while (todo != 0) {   // uniform
     const int k = kf_begin + __builtin_ctzll(todo);
     todo &= todo - 1;
     KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
-    if constexpr (kDesc || (BSLAM_HOIST_GEO && kPoseR > 4)) BSLAM_HOIST_KF_TRANSLATION(kf);
+    if constexpr (kDesc || kPoseR > 4) BSLAM_HOIST_KF_TRANSLATION(kf);
     float acc[kRow];
     // Every live accumulator is zeroed by its own opaque instruction.  Written as acc[i] = 0.f the optimiser knows all of
     // them to be one value: it folds the first surfel's fma(wj, J, 0) into a multiply and then has to materialise the zeros a
@@ -267,19 +268,12 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     const bool any = count != 0;   // uniform
     float total = 0.f;
     constexpr int kLive = kCost ? kRowCost + 1 : kRowCost;   // 21 H, 6 b (, cost); the count column is filled in below
-#if BSLAM_REDUCE_2STAGE
-    int my_col = (int)(lane / (16 / kRedCols)) + ((kRedCols == 4 && (lane & 1)) ? 16 : 0);
-    bool writer = (lane % (16 / kRedCols)) < (kRedCols == 4 ? 2 : 1);
-    if (any) total = wave_column_sums_lds2<kLive, kRedCols>(acc, red_tile[wave], &my_col, &writer);
+    int my_col;    // the column this lane ends up with, and whether it is the lane that stores it
+    bool writer;
+    wave_column_sums_owner<kLive, kRedCols>(&my_col, &writer);
+    if (any) total = wave_column_sums_lds<kLive, kRedCols>(acc, red_tile[wave]);
     if (my_col == kRowCount) total = (float)count;   // <= 64 * kPoseR: exact
     if (writer) row_stash[stash_buf][stashed][wave][my_col] = total;
-#else
-    if (any) total = wave_column_sums_lds<kLive, kRedCols>(acc, red_tile[wave]);
-    constexpr int kRedLanes = 64 / kRedCols;   // lanes per column: lane (g, i) = (lane / kRedLanes, lane % kRedLanes) holds column kRedCols i + g
-    const int my_col = kRedCols * (lane % kRedLanes) + lane / kRedLanes;
-    if (my_col == kRowCount) total = (float)count;   // <= 64 * kPoseR: exact
-    if ((lane % kRedLanes) < kRow / kRedCols) row_stash[stash_buf][stashed][wave][my_col] = total;
-#endif
     if (threadIdx.x == 0) stash_kf[stash_buf][stashed] = k;
     if (++stashed == kPoseStashGroup) { flush_rows(stashed); stashed = 0; stash_buf ^= 1; }
   }
