@@ -14,9 +14,6 @@
 
 #include "../../include/badslam_hip.h"
 
-#ifndef BSLAM_TRY_GEOM_HOIST
-#define BSLAM_TRY_GEOM_HOIST 0
-#endif
 namespace bslam {
 
 struct f3 { float x, y, z; };
@@ -713,6 +710,7 @@ __device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, fl
 #define BSLAM_TO_VGPR(x) do { float v_; asm volatile("v_mov_b32 %0, %1" : "=v"(v_) : "s"(x)); (x) = v_; } while (0)
 #define BSLAM_HOIST_KF_TRANSLATION(kf) do { BSLAM_TO_VGPR((kf).frame_T_global.m[3]); BSLAM_TO_VGPR((kf).frame_T_global.m[7]); BSLAM_TO_VGPR((kf).frame_T_global.m[11]); } while (0)
 #define BSLAM_HOIST_CAM_CENTRES(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); BSLAM_TO_VGPR((c).ccx); BSLAM_TO_VGPR((c).ccy); } while (0)
+#define BSLAM_HOIST_UNPROJECTION_CENTRE(c) do { BSLAM_TO_VGPR((c).cx_inv); BSLAM_TO_VGPR((c).cy_inv); } while (0)   // nx_of / ny_of
 #define BSLAM_HOIST_DEPTH_CAM_CENTRE(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); } while (0)   // kernels that never sample the colour image
 
 // ---------------------------------------------------------------------------------------------

@@ -372,18 +372,15 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c_in, 
     gp[r] = mk3(s.x[j], s.y[j], s.z[j]);
     gn[r] = unpack_normal(s.normal[j]);
   }
-#if BSLAM_TRY_GEOM_HOIST
   BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
-#endif
+  BSLAM_HOIST_UNPROJECTION_CENTRE(c);
   {
     float sx[R], sy[R], sz[R], cnt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) sx[r] = sy[r] = sz[r] = cnt[r] = 0.f;
     BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
       KfDev kf = kfs[k];
-#if BSLAM_TRY_GEOM_HOIST
       BSLAM_HOIST_KF_TRANSLATION(kf);
-#endif
       const float* Rm = kf.global_R_frame;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -411,9 +408,7 @@ __global__ __launch_bounds__(256) void geometry_position_kernel(CamConsts c_in, 
   for (int r = 0; r < R; ++r) H[r] = b[r] = 0.f;
   BSLAM_FOR_VISITED_KEYFRAMES(k, 0, kf_count, R) {
     KfDev kf = kfs[k];
-#if BSLAM_TRY_GEOM_HOIST
     BSLAM_HOIST_KF_TRANSLATION(kf);
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       Proj p;
@@ -547,6 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BSLAM_GEOM_
     for (int q = 0; q < kAcc; ++q) a[r][q] = (!first_chunk && on[r]) ? acc[(size_t)q * acc_pitch + j] : 0.f;
   }
   if constexpr (kPass == 1) BSLAM_HOIST_CAM_CENTRES(c);
+  if constexpr (kPass == 1) BSLAM_HOIST_UNPROJECTION_CENTRE(c);
   BSLAM_FOR_VISITED_KEYFRAMES(k, k_begin, k_end, R) {
     KfDev kf = kfs[k];
     if constexpr (kPass == 1) BSLAM_HOIST_KF_TRANSLATION(kf);

@@ -219,6 +219,8 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   for (int i = 0; i < kPcgGlobRow; ++i) glob[i] = 0.f;
 
   if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
+  else BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
+  BSLAM_HOIST_UNPROJECTION_CENTRE(c);
   int stashed = 0;   // keyframes in the current stash (uniform)
   int buf = 0;
   for (int k0 = 0; k0 < kf_count; k0 += 64) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kPcgThreads) void pcg_init_kernel(
   for (; todo != 0; todo &= todo - 1) {
     const int k = k0 + __builtin_ctzll(todo);
     KfDev kf = kfs[k];
-    if constexpr (kDesc) BSLAM_HOIST_KF_TRANSLATION(kf);
+    BSLAM_HOIST_KF_TRANSLATION(kf);
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pose[kPcgPoseRow];
@@ -489,6 +491,8 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   if (kIntr && P.optimize_color_intr) for (int j = 0; j < 4; ++j) pci[j] = P.p[P.color_intr_start + j];
 
   if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
+  else BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
+  BSLAM_HOIST_UNPROJECTION_CENTRE(c);
   int stashed = 0;   // keyframes in the current stash (uniform)
   int buf = 0;
   for (int k0 = 0; k0 < kf_count; k0 += 64) {
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(kPcgThreads) __attribute__((amdgpu_waves_per_eu(kDe
   for (; todo != 0; todo &= todo - 1) {
     const int k = k0 + __builtin_ctzll(todo);
     KfDev kf = kfs[k];
-    if constexpr (kDesc) BSLAM_HOIST_KF_TRANSLATION(kf);
+    BSLAM_HOIST_KF_TRANSLATION(kf);
     const uint32_t kf_idx = kf_pose_unknown_index(P.gauge_kf, kf.id);
     const bool opt_pose = P.optimize_poses && kf_idx != kInvalidUnknown;
     float pp[6] = {0, 0, 0, 0, 0, 0};
