@@ -131,6 +131,7 @@ SIGNATURES = {
     "bslam_comm_destroy": (C.c_int, [C.c_void_p]),
     "bslam_comm_query": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
     "bslam_set_culling": (C.c_int, [C.c_void_p, C.c_int]),
+    "bslam_set_pose_keyframe_list": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_debug_cull_stats": (C.c_int, [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]),
     "bslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bslam_profile_read": (C.c_int, [C.c_void_p, C.c_int, P(C.c_int32), P(C.c_float)]),

@@ -431,7 +431,7 @@ static unsigned long long* cull_stats_ptr(bslam_context* ctx) {
 static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int use_depth, int use_desc, const CamConsts& c,
                                   int kf_count, uint32_t surfels_size, const bslam_buffer2d* surfels, const PoseState* states,
                                   int* tiles_out, bool reduce_rows = true, const SurfelWork* work = nullptr, int* kfs_per_block_out = nullptr,
-                                  bool want_cost = false) {
+                                  bool want_cost = false, const int* kf_list = nullptr, int kf_list_bound = 0) {
   SurfelWork local;
   int rc = BSLAM_OK;
   if (!work) {
@@ -460,7 +460,10 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   if (kfs_per_block_out) *kfs_per_block_out = per_block;
   if ((rc = ctx->vis.reserve((size_t)chunks * sc.slots * sizeof(VisWord)))) return rc;
   VisWord* vis = (VisWord*)ctx->vis.ptr;
-  dim3 grid(8u * sc.slots_per_xcd * chunks);
+  // kf_list: the launch walks the device-side list of unconverged keyframes (batched loop); kf_list_bound = an upper bound of its
+  // length known to the host (the count of an earlier iteration), which sizes the grid -- the visit words keep room for all chunks
+  const unsigned launch_chunks = kf_list ? (unsigned)std::max(1, (std::min(kf_list_bound, kf_count) + per_block - 1) / per_block) : chunks;
+  dim3 grid(8u * sc.slots_per_xcd * launch_chunks);
   const SurfelRows rows = work->rows;
   const KfDev* kfs = (const KfDev*)ctx->kf_table.ptr;
   float* partials = (float*)ctx->partials.ptr;
@@ -471,8 +474,8 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   const bool cost = want_cost;
 #define BSLAM_LAUNCH_POSE(DEPTH, DESC, R)                                                                                                        \
   do {                                                                                                                                           \
-    if (cost) hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, true>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis);  \
-    else hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, false>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis); \
+    if (cost) hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, true>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis, kf_list);  \
+    else hipLaunchKernelGGL((pose_accumulate_kernel<DEPTH, DESC, R, false>), grid, dim3(kPoseThreads), debug_lds, stream, c, kfs, kf_count, per_block, sc, rows, partials, rows_per_kf, states, vis, kf_list); \
   } while (0)
   if (use_depth && use_desc) BSLAM_LAUNCH_POSE(true, true, kPoseRDesc);
   else if (use_depth && pose_surfels_per_thread(false, surfels_size) == kPoseRGeoLarge) BSLAM_LAUNCH_POSE(true, false, kPoseRGeoLarge);
@@ -485,7 +488,7 @@ static int launch_pose_accumulate(bslam_context* ctx, hipStream_t stream, int us
   // sums of counts are formed per row as floats: a (slot, wave) row holds <= 64 * kPoseR residuals, a thread's
   // share at most rows / 32 * 256 -- exact in fp32 up to 2^24
   hipLaunchKernelGGL(pose_reduce_rows_kernel, dim3((unsigned)kf_count), dim3(1024), (unsigned)visit_map_bytes(tiles), stream, (const float*)partials, rows_per_kf, kf_count,
-                     (float*)ctx->coeffs.ptr, states, (const VisWord*)vis, per_block, cull_stats_ptr(ctx));
+                     (float*)ctx->coeffs.ptr, states, (const VisWord*)vis, per_block, cull_stats_ptr(ctx), kf_list ? kf_list + 1 + kf_count : nullptr);
   BSLAM_HIP_TRY(hipGetLastError());
   return BSLAM_OK;
 }
@@ -692,6 +695,13 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable) {
 int bslam_set_culling(bslam_context* ctx, int enable) {
   if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "context is null");
   ctx->culling = enable != 0;
+  return BSLAM_OK;
+}
+
+int bslam_set_pose_keyframe_list(bslam_context* ctx, int min_keyframes) {
+  if (!ctx) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null context");
+  if (min_keyframes < 0) return fail(BSLAM_ERR_INVALID_ARGUMENT, "min_keyframes must be >= 0");
+  ctx->pose_list_min_keyframes = min_keyframes;
   return BSLAM_OK;
 }
 
@@ -971,6 +981,21 @@ int bslam_estimate_frame_poses_batched(
   SurfelWork work;   // schedule + (sorted) surfel rows: the surfels do not change during the loop
   if (surfels_size > 0 && (rc = prepare_surfels(ctx, stream, surfels, surfels_size, pose_surfels_per_thread(use_descriptor_residuals != 0, surfels_size), keyframe_count, &work, use_descriptor_residuals != 0))) return rc;
 
+  // Long keyframe lists: the accumulation walks a device-side list of the keyframes that are still unconverged, rebuilt behind
+  // every solve (pose_active_list_kernel: one small block between two launches that take milliseconds), so that its chunks -- and
+  // with them the number of workgroups of a launch -- shrink with the work that is left.  On a sequence most keyframes converge
+  // in two or three iterations and a few stragglers run to the cap: K = 1000 on the trajectory stack spends 28 of its 30 launches
+  // on fewer than 50 keyframes.  Short lists (the per-iteration kernel would cost more than it saves) walk the table itself
+  // (bslam_set_pose_keyframe_list: from 64 keyframes on by default).
+  int* d_list = nullptr;
+  if (surfels_size > 0 && ctx->pose_list_min_keyframes > 0 && keyframe_count >= ctx->pose_list_min_keyframes) {
+    if ((rc = ctx->pose_list.reserve((size_t)(1 + 2 * keyframe_count) * sizeof(int)))) return rc;
+    d_list = (int*)ctx->pose_list.ptr;
+    hipLaunchKernelGGL(pose_active_list_kernel, dim3(1), dim3(kActiveListThreads), 0, stream, keyframe_count, (const PoseState*)d_states, d_list);
+    BSLAM_HIP_TRY(hipGetLastError());
+  }
+  int known_active = keyframe_count;   // upper bound of the list's length: the count the host has read back last (lags the device)
+
   // One Gauss-Newton iteration of all unconverged keyframes, ending with the number of keyframes still
   // unconverged on its way to h_active[it % 4].
   auto enqueue_iteration = [&](int it) -> int {
@@ -980,19 +1005,21 @@ int bslam_estimate_frame_poses_batched(
     // Slot 0 was zeroed by pose_init_kernel, later slots are zeroed by the previous iteration's solve kernel.
     if (fused) {
       int tiles = 0, per_block = 1;
-      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work, &per_block);
+      int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, false, &work, &per_block,
+                                     false, d_list, known_active);
       if (r) return r;
       {
         ProfScope prof(ctx, stream, BSLAM_PROF_POSE_REDUCE);
         hipLaunchKernelGGL(pose_reduce_solve_kernel, dim3((unsigned)keyframe_count), dim3(kReduceSolveThreads), (unsigned)visit_map_bytes(tiles), stream, (const float*)ctx->partials.ptr,
                            tiles * kPoseRowsPerSlot, keyframe_count, d_states, (KfDev*)ctx->kf_table.ptr, d_active + slot, d_active + ((it + 1) & 3),
-                           (const VisWord*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx));
+                           (const VisWord*)ctx->vis.ptr, per_block, cull_stats_ptr(ctx), d_list ? d_list + 1 + keyframe_count : nullptr);
       }
       BSLAM_HIP_TRY(hipGetLastError());
     } else {
       if (surfels_size > 0) {
         int tiles = 0;
-        int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, true, &work);
+        int r = launch_pose_accumulate(ctx, stream, use_depth_residuals, use_descriptor_residuals, c, keyframe_count, surfels_size, surfels, d_states, &tiles, true, &work, nullptr,
+                                       false, d_list, known_active);
         if (r) return r;
       } else {
         int r = ctx->coeffs.reserve((size_t)keyframe_count * kRow * sizeof(float));
@@ -1021,6 +1048,10 @@ int bslam_estimate_frame_poses_batched(
     BSLAM_HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->solve_done[slot], 0));
     BSLAM_HIP_TRY(hipMemcpyAsync(h_active + slot, d_active + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream));
     BSLAM_HIP_TRY(hipEventRecord(ctx->iter_done[slot], ctx->copy_stream));
+    if (d_list) {   // the list the NEXT iteration's accumulation walks (behind the event: the flag does not wait for it)
+      hipLaunchKernelGGL(pose_active_list_kernel, dim3(1), dim3(kActiveListThreads), 0, stream, keyframe_count, (const PoseState*)d_states, d_list);
+      BSLAM_HIP_TRY(hipGetLastError());
+    }
     return BSLAM_OK;
   };
   // The host learns "all converged" one iteration late: iteration it + 1 is already enqueued while the flag of
@@ -1032,6 +1063,7 @@ int bslam_estimate_frame_poses_batched(
     if (it + 1 < max_iterations && (rc = enqueue_iteration(it + 1))) return rc;
     BSLAM_HIP_TRY(hipEventSynchronize(ctx->iter_done[it & 3]));
     if (h_active[it & 3] == 0) break;
+    known_active = std::min(known_active, h_active[it & 3]);   // convergence is final: later lists are no longer than this
   }
   BSLAM_HIP_TRY(hipMemcpyAsync(ctx->staging2.ptr, d_states, state_bytes, hipMemcpyDeviceToHost, stream));
   BSLAM_HIP_TRY(hipStreamSynchronize(stream));

@@ -163,8 +163,10 @@ struct bslam_context {
   bool sorted_key_bounds = false;
   uint64_t sorted_key_perm_serial = 0;   // the permutation the copy was made with
   uint64_t perm_serial = 0;              // counts rebuilds of `perm`
+  bslam::Slab pose_list;     // batched pose loop: int n | int list[K] (the unconverged keyframes, ascending) | int pos[K] (place in the list, or -1)
   bslam::Slab vis;           // uint64[chunks][slots]: keyframes of a chunk (<= 64) a work slot visited in the last pose_accumulate launch
   bool culling = true;       // block-level frustum culling in the pair kernels (bslam_set_culling)
+  int pose_list_min_keyframes = 64;   // batched pose loop: walk the list of unconverged keyframes from this many keyframes on (bslam_set_pose_keyframe_list; 0: never)
   const void* perm_key_ptr = nullptr;
   uint32_t perm_key_size = 0;
   size_t perm_key_pitch = 0;

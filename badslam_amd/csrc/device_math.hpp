@@ -824,10 +824,13 @@ __device__ __forceinline__ bool box_outside_frustum(const CamConsts& c, const fl
 // (`wanted` is the caller's own per-lane condition -- not converged, not inactive; sc.bounds == nullptr means no culling).
 // Uniform across the wave.  The slot's box is rebuilt from the granule boxes on every call (a few uniform loads per 64
 // keyframes) rather than kept live across the caller's keyframe loop, where it would cost registers.
+// lane_kf: the keyframe of this lane where the caller walks a LIST of keyframes (place k0 + lane of the list), else -1: keyframe
+// k0 + lane itself.
 __device__ __forceinline__ unsigned long long keyframes_to_visit(const CamConsts& c, const KfDev* __restrict__ kfs, int k0, int k_end, const Schedule& sc,
-                                                                 uint32_t slot, int R, bool wanted) {
-  const int k = k0 + (int)(threadIdx.x & 63u);
-  bool visit = k < k_end && wanted;
+                                                                 uint32_t slot, int R, bool wanted, int lane_kf = -1) {
+  const int place = k0 + (int)(threadIdx.x & 63u);
+  const int k = lane_kf >= 0 ? lane_kf : place;
+  bool visit = place < k_end && wanted;
   if (sc.bounds != nullptr) {
     uint32_t s_ = slot;
     asm volatile("" : "+s"(s_));   // keeps the box's loads inside the caller's loop over keyframe batches

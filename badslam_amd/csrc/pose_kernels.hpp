@@ -122,8 +122,14 @@ constexpr int kPoseStashGroupGeo = 4, kPoseStashGroupDesc = BSLAM_POSE_STASH_GRO
 template <bool kDepth, bool kDesc, int kPoseR, bool kCost>
 __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accumulate_kernel(
     CamConsts c_in, const KfDev* __restrict__ kfs, int kf_count, int kfs_per_block, Schedule sc,
-    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, VisWord* __restrict__ vis) {
+    SurfelRows s, float* __restrict__ partials, int rows_per_kf, const PoseState* __restrict__ states, VisWord* __restrict__ vis,
+    const int* __restrict__ kf_list) {
   CamConsts c = c_in;
+  // kf_list (batched Gauss-Newton loop on long keyframe lists): {n, list[n]} = the keyframes that are still unconverged, in
+  // ascending order (pose_active_list_kernel).  The chunks of a launch then cut that LIST, not the keyframe table, so a late
+  // iteration with a handful of stragglers runs one chunk's worth of workgroups instead of every chunk's, each of which would only
+  // start, find its keyframes converged and leave.  nullptr: the chunks cut the table itself.
+  const int kf_places = kf_list ? kf_list[0] : kf_count;
   // 1-D grid of 8 * slots_per_xcd * chunks blocks: block b -> XCD lane x = b % 8; within an XCD the
   // blocks run chunk-major over that XCD's range of surfel slots.
   const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
@@ -132,7 +138,8 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   if (!slot_of_block(sc, (local << 3) | xcd, &slot)) return;
   const int tile = (int)slot;
   const int kf_begin = (int)chunk * kfs_per_block;
-  const int kf_end = min(kf_count, kf_begin + kfs_per_block);
+  if (kf_begin >= kf_places) return;   // the host sized the grid by an older (larger) count of unconverged keyframes
+  const int kf_end = min(kf_places, kf_begin + kfs_per_block);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // Which keyframes of the chunk (<= 64) this block visits, decided for all of them at once, one keyframe per lane: not
@@ -141,9 +148,10 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   // (pose_reduce_*_kernel) only read the partial rows of visited (slot, keyframe) pairs, the others are never written.
   unsigned long long todo;
   {
-    const int k = kf_begin + lane;
-    const bool wanted = states == nullptr || (k < kf_end && !states[k].converged);
-    todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc, slot, kPoseR, wanted);
+    const int place = kf_begin + lane;
+    const int k = (kf_list && place < kf_end) ? kf_list[1 + place] : place;
+    const bool wanted = states == nullptr || (place < kf_end && !states[k].converged);
+    todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc, slot, kPoseR, wanted, kf_list ? k : -1);
   }
   if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = todo;
   if (todo == 0) return;   // leaves before touching the surfels
@@ -194,9 +202,16 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
 
   if constexpr (kDesc) BSLAM_HOIST_CAM_CENTRES(c);
   else if constexpr (kPoseR > 4) BSLAM_HOIST_DEPTH_CAM_CENTRE(c);
+  // the list entry of the next keyframe to visit is fetched (a scalar load) one visit ahead
+  int k_next = kf_begin + __builtin_ctzll(todo);
+  if (kf_list) k_next = kf_list[1 + k_next];
   while (todo != 0) {   // uniform
-    const int k = kf_begin + __builtin_ctzll(todo);
+    const int k = k_next;
     todo &= todo - 1;
+    if (todo != 0) {
+      k_next = kf_begin + __builtin_ctzll(todo);
+      if (kf_list) k_next = kf_list[1 + k_next];
+    }
     KfDev kf = kfs[k];   // by value: the uniform fields are fetched once per keyframe, ahead of the per-surfel branches
     if constexpr (kDesc || kPoseR > 4) BSLAM_HOIST_KF_TRANSLATION(kf);
     float acc[kRow];
@@ -387,7 +402,8 @@ __device__ __forceinline__ float column_share_of_rows(const float* __restrict__ 
 // that repeated in-place all-reduces never grow stale values.
 __global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                float* __restrict__ coeffs, const PoseState* __restrict__ states,
-                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
+                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats,
+                                                               const int* __restrict__ kf_pos) {
   const int k = blockIdx.x;
   if (states != nullptr && states[k].converged) {
     if (threadIdx.x < kRow) coeffs[(size_t)k * kRow + threadIdx.x] = 0.f;
@@ -397,7 +413,8 @@ __global__ __launch_bounds__(1024) void pose_reduce_rows_kernel(const float* __r
   extern __shared__ unsigned long long vmap[];   // visit_map_bytes(slots)
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int slots = rows_per_kf / kRowsPerSlot;
-  const uint32_t visiting = build_visit_map(vis + (size_t)(k / kfs_per_block) * slots, (uint32_t)(k % kfs_per_block), slots, vmap);
+  const int place = kf_pos ? kf_pos[k] : k;   // the keyframe's place in the list the accumulation walked (its chunk and bit)
+  const uint32_t visiting = build_visit_map(vis + (size_t)(place / kfs_per_block) * slots, (uint32_t)(place % kfs_per_block), slots, vmap);
   if (stats != nullptr && threadIdx.x == 0) { atomicAdd(&stats[0], (unsigned long long)slots); atomicAdd(&stats[1], (unsigned long long)visiting); }
   sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf, vmap);   // the count column: <= 256 per row, exact in fp32 up to 65k rows
   __syncthreads();
@@ -594,6 +611,44 @@ __global__ void pose_init_kernel(int kf_count, const PoseState* __restrict__ sta
   se3_inverse_matrix(Quat{st.q[0], st.q[1], st.q[2], st.q[3]}, mk3(st.t[0], st.t[1], st.t[2]), kfs[k].frame_T_global.m);
 }
 
+// The keyframes that are still unconverged, in ascending order: out = {n, list[n] (entries up to kf_count), pos[kf_count]} with
+// pos[k] = place of keyframe k in the list, or -1.  One block; runs between the solve of one Gauss-Newton iteration and the
+// accumulation of the next (and once behind pose_init_kernel).
+constexpr int kActiveListThreads = 1024;
+__global__ __launch_bounds__(kActiveListThreads) void pose_active_list_kernel(int kf_count, const PoseState* __restrict__ states, int* __restrict__ out) {
+  __shared__ int wave_total[kActiveListThreads / 64];
+  __shared__ int base;
+  int* list = out + 1;
+  int* pos = out + 1 + kf_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < kf_count; k0 += kActiveListThreads) {
+    const int k = k0 + (int)threadIdx.x;
+    const bool active = k < kf_count && !states[k].converged;
+    const unsigned long long mask = __ballot(active);
+    if (lane == 0) wave_total[wave] = __builtin_popcountll(mask);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wave_total[w];
+    if (active) {
+      const int place = before + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      list[place] = k;
+      pos[k] = place;
+    } else if (k < kf_count) {
+      pos[k] = -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = base;
+      for (int w = 0; w < kActiveListThreads / 64; ++w) t += wave_total[w];
+      base = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = base;
+}
+
 // One Gauss-Newton update per keyframe (BS/direct_ba_alternating.cc:206-233).
 __global__ void pose_solve_kernel(const float* __restrict__ coeffs, int kf_count, PoseState* __restrict__ states,
                                   KfDev* __restrict__ kfs, int* __restrict__ active_count, int* __restrict__ next_active_count) {
@@ -635,7 +690,8 @@ constexpr int kReduceSolveThreads = 1024;
 __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(const float* __restrict__ partials, int rows_per_kf, int kf_count,
                                                                                PoseState* __restrict__ states, KfDev* __restrict__ kfs,
                                                                                int* __restrict__ active_count, int* __restrict__ next_active_count,
-                                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats) {
+                                                                               const VisWord* __restrict__ vis, int kfs_per_block, unsigned long long* __restrict__ stats,
+                                                                               const int* __restrict__ kf_pos) {
   const int k = blockIdx.x;
   if (k == 0 && threadIdx.x == 0) *next_active_count = 0;   // the next iteration's counter (last read four iterations ago)
   if (states[k].converged) return;   // uniform
@@ -644,7 +700,8 @@ __global__ __launch_bounds__(kReduceSolveThreads) void pose_reduce_solve_kernel(
   extern __shared__ unsigned long long vmap[];   // visit_map_bytes(slots)
   const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int slots = rows_per_kf / kRowsPerSlot;
-  const uint32_t visiting = build_visit_map(vis + (size_t)(k / kfs_per_block) * slots, (uint32_t)(k % kfs_per_block), slots, vmap);
+  const int place = kf_pos ? kf_pos[k] : k;   // the keyframe's place in the list the accumulation walked (its chunk and bit)
+  const uint32_t visiting = build_visit_map(vis + (size_t)(place / kfs_per_block) * slots, (uint32_t)(place % kfs_per_block), slots, vmap);
   if (stats != nullptr && threadIdx.x == 0) { atomicAdd(&stats[0], (unsigned long long)slots); atomicAdd(&stats[1], (unsigned long long)visiting); }
   sm[sub][col] = column_share_of_rows(partials + (size_t)k * rows_per_kf * kRow + col, sub, rows_per_kf, vmap);
   __syncthreads();

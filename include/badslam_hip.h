@@ -184,6 +184,12 @@ int bslam_set_xcd_schedule(bslam_context* ctx, int enable);
  * (ProjectSurfelToImage, BS/util.cuh:86-99) is ever skipped -- so every output is bit-identical with and without it).  The
  * reference spends a thread on every (surfel, keyframe) pair (BS/kernel_opt_pose.cu:263-275).  0 = visit every pair. */
 int bslam_set_culling(bslam_context* ctx, int enable);
+/* Batched pose loop (bslam_estimate_frame_poses_batched) on keyframe lists of at least `min_keyframes` keyframes: every
+ * Gauss-Newton iteration walks a device-side list of the keyframes that are still unconverged instead of the whole keyframe
+ * table, so the number of workgroups of an iteration follows the work that is left (on a sequence most keyframes converge in
+ * two or three iterations and a few run to the cap of 30, BS/direct_ba_alternating.cc:130).  Results are bit-identical either
+ * way.  Default 64; 0 = never (every iteration launches workgroups for every keyframe, converged or not). */
+int bslam_set_pose_keyframe_list(bslam_context* ctx, int min_keyframes);
 /* (work slot, keyframe) pairs the pose kernel's launches tested / skipped since the last call (HOST out; counted while
  * bslam_profile_enable is on; synchronises the device and resets the counters). */
 int bslam_debug_cull_stats(bslam_context* ctx, uint64_t* tested, uint64_t* culled);

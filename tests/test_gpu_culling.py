@@ -262,3 +262,41 @@ def test_mixed_keyframe_activations_with_and_without_culling():
     assert 0 < out[1][0].sum() < S                                     # surfels only seen by inactive / covisible keyframes stay inactive
     inactive = np.array([k % 3 == 1 for k in range(K)])
     assert (out[1][3][inactive] == 0).all() and (out[1][3][~inactive] > 0).all()
+
+
+@pytest.mark.parametrize("kind,K,use_desc", [("trajectory", 72, False), ("trajectory", 130, True), ("dense", 64, False)])
+def test_batched_pose_loop_is_bit_identical_with_and_without_the_keyframe_list(kind, K, use_desc):
+    """From 64 keyframes on the batched Gauss-Newton loop walks a device-side list of the keyframes that are still unconverged
+    (bslam_set_pose_keyframe_list): chunks cut the list instead of the keyframe table, the grid shrinks with it.  Which keyframes
+    share a chunk changes from iteration to iteration; poses, iteration counts and convergence flags must not.  The start poses
+    are perturbed by very different amounts (some keyframes start at their rendered pose and stop after one step, some need many),
+    so that the list shrinks unevenly, and one keyframe is INACTIVE (never in the list)."""
+    dev = synthetic.TorchStack(K, "cuda:0", kind=kind, border_valid=True)
+    run = Runner(dev, use_desc)
+    rng = np.random.default_rng(23)
+    inits = (abi.SE3f * K)()
+    for k in range(K):
+        scale = (0.0, 0.2, 1.0, 3.0)[k % 4]
+        xi = np.concatenate([rng.choice([-1, 1], 3) * 0.004 * scale, rng.choice([-1, 1], 3) * 0.0008 * scale])
+        inits[k] = dev.stack.pose(k, xi)[0]
+    kfs = run.views()
+    kfs[5].activation = abi.KF_INACTIVE
+    out = {}
+    noop = abi.ALLREDUCE_FN(lambda user, ptr, count, stream: 0)   # one rank: the sum across ranks is the identity
+    # default, never, always; "hook": the kernel sequence of a surfel-sharded run (row sums, exchange, solve as separate kernels)
+    for name, threshold, hook in (("default", 64, None), ("never", 0, None), ("always", 1, None), ("hook", 64, noop), ("hook, never", 0, noop)):
+        badslam_amd.check(run.L.bslam_set_pose_keyframe_list(run.ctx.handle, threshold))
+        dp, sb = dev.depth_params(), dev.buf(dev.surfels)
+        poses = (abi.SE3f * K)()
+        C.memmove(poses, inits, C.sizeof(poses))
+        iters, conv = (C.c_int32 * K)(), (C.c_int32 * K)()
+        badslam_amd.check(run.L.bslam_estimate_frame_poses_batched(run.ctx.handle, run.stream, 1, int(use_desc), C.byref(run.cam), C.byref(run.cam), C.byref(dp), K, kfs,
+                                                                   dev.surfels_size, C.byref(sb), 12, poses, iters, conv, hook if hook else C.cast(None, abi.ALLREDUCE_FN), None))
+        out[name] = (bits(np.array([[*p.q, *p.t] for p in poses], np.float32)), list(iters), list(conv))
+    badslam_amd.check(run.L.bslam_set_pose_keyframe_list(run.ctx.handle, 64))
+    for name in ("default", "always", "hook", "hook, never"):
+        assert np.array_equal(out[name][0], out["never"][0]), name
+        assert out[name][1] == out["never"][1] and out[name][2] == out["never"][2], name
+    iters = out["never"][1]
+    assert iters[5] == 0                                      # the inactive keyframe is never touched
+    assert len(set(iters)) >= 3, sorted(set(iters))           # keyframes leave the list at different iterations

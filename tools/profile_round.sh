@@ -15,6 +15,8 @@ echo "bench done"; tail -c 300 $O/bench_default.json
 python bench.py $ONE --keyframes 200 --photometric 0 > $O/bench_k200_geo.json 2> $O/bench_k200_geo.err
 python bench.py $ONE --keyframes 1000 --photometric 0 --steps 3 --warmup 1 > $O/bench_k1000_geo.json 2> $O/bench_k1000_geo.err
 python bench.py $ONE --keyframes 50 --photometric 1 > $O/bench_k50_photo.json 2> $O/bench_k50_photo.err
+# BASELINE.json configs[4]'s regime on the smooth-trajectory stack ("a smooth 1000-pose trajectory for C5")
+python bench.py $ONE --scene trajectory --keyframes 1000 --photometric 0 --steps 3 --warmup 1 > $O/bench_k1000_trajectory_geo.json 2> $O/bench_k1000_trajectory_geo.err
 echo "extra bench lines done"
 fi
 if [ $STAGE = all ] || [ $STAGE = stats ]; then
