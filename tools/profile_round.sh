@@ -46,6 +46,8 @@ fi
 # in separate GPU calls -- from the copy committed under profiles/)
 for w in k300_photo k300_trajectory k50_geo k50_photo; do
   [ -d $O/pmc_$w ] || continue
+  # (a stage run earlier in the same session has had its counter files summarised and deleted: leave its summaries alone)
+  [ -n "$(find $O/pmc_$w -name '*counter_collection.csv' | head -1)" ] || continue
   S=$(ls $O/stats_$w/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$S" ] || S=$R/profiles/${TAG}_kernel_stats_$w.csv
   python tools/pmc_summary.py $O/pmc_$w $S > $O/pmc_summary_$w.txt 2>&1 || true
