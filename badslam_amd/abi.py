@@ -140,6 +140,7 @@ SIGNATURES = {
     "bslam_assign_colors": (C.c_int, [C.c_void_p, C.c_void_p, _CAM, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF]),
     "bslam_debug_decode_normals": (C.c_int, [C.c_void_p, C.c_void_p, P(C.c_float)]),
     "bslam_debug_jacobians": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
+    "bslam_debug_wave_column_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bslam_debug_count_pairs": (C.c_int, [
         C.c_void_p, C.c_void_p, _CAM, _DP, C.c_int, _KFS, C.c_uint32, _BUF, P(C.c_uint64), P(C.c_uint64)]),
     "bslam_accumulate_pose_estimation_coeffs": (C.c_int, [

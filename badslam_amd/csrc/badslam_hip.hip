@@ -808,6 +808,30 @@ int bslam_debug_decode_normals(bslam_context* ctx, void* stream_, float* out_xyz
   return BSLAM_OK;
 }
 
+int bslam_debug_wave_column_sums(bslam_context* ctx, void* stream_, int live_columns, int columns_per_round, const float* in, float* out) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ctx || !in || !out) return fail(BSLAM_ERR_INVALID_ARGUMENT, "null argument");
+  BSLAM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t in_bytes = 64 * kRow * sizeof(float), out_bytes = kRow * sizeof(float);
+  int rc = ctx->coeffs.reserve(in_bytes + out_bytes);
+  if (rc) return rc;
+  float* d_in = (float*)ctx->coeffs.ptr;
+  float* d_out = (float*)((uint8_t*)ctx->coeffs.ptr + in_bytes);
+  BSLAM_HIP_TRY(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, stream));
+  BSLAM_HIP_TRY(hipMemcpyAsync(d_out, out, out_bytes, hipMemcpyHostToDevice, stream));
+#define BSLAM_PROBE(LIVE, COLS) \
+  if (live_columns == LIVE && columns_per_round == COLS) hipLaunchKernelGGL((wave_column_sums_probe_kernel<LIVE, COLS>), dim3(1), dim3(64), 0, stream, (const float*)d_in, d_out); else
+  // the configurations the kernels use: pose rows (27 live columns, 28 with the cost) in rounds of 4 (photometric) and 8
+  // (geometry-only), the PCG kernels' 6 / 12 pose entries in rounds of 4
+  BSLAM_PROBE(27, 4) BSLAM_PROBE(28, 4) BSLAM_PROBE(27, 8) BSLAM_PROBE(28, 8) BSLAM_PROBE(6, 4) BSLAM_PROBE(12, 4)
+  return fail(BSLAM_ERR_INVALID_ARGUMENT, "no kernel sums %d columns in rounds of %d", live_columns, columns_per_round);
+#undef BSLAM_PROBE
+  BSLAM_HIP_TRY(hipGetLastError());
+  BSLAM_HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+  BSLAM_HIP_TRY(hipStreamSynchronize(stream));
+  return BSLAM_OK;
+}
+
 int bslam_debug_jacobians(bslam_context* ctx, void* stream_, int kind, int count, const float* in, float* out) {
   hipStream_t stream = (hipStream_t)stream_;
   static const int kIn[8] = {10, 1, 21, 11, 14, 8, 10, 1}, kOut[8] = {7, 1, 7, 9, 1, 4, 7, 2};

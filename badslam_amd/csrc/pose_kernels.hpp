@@ -147,13 +147,18 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
   // bounding box of the slot's surfels reaches into the keyframe's image.  The word goes to vis[chunk][slot]: the row sums
   // (pose_reduce_*_kernel) only read the partial rows of visited (slot, keyframe) pairs, the others are never written.
   unsigned long long todo;
-  {
+  // decided by the first wave and handed to the others through LDS: for the workgroups that leave here (nine in ten on a
+  // trajectory) the three other waves' copies of the test were the larger part of their work (survey-range stack -1.5 %)
+  __shared__ unsigned long long todo_shared;
+  if (wave == 0) {
     const int place = kf_begin + lane;
     const int k = (kf_list && place < kf_end) ? kf_list[1 + place] : place;
     const bool wanted = states == nullptr || (place < kf_end && !states[k].converged);
     todo = keyframes_to_visit(c, kfs, kf_begin, kf_end, sc, slot, kPoseR, wanted, kf_list ? k : -1);
+    if (lane == 0) { todo_shared = todo; vis[(size_t)chunk * sc.slots + slot] = todo; }
   }
-  if (threadIdx.x == 0) vis[(size_t)chunk * sc.slots + slot] = todo;
+  __syncthreads();
+  todo = todo_shared;
   if (todo == 0) return;   // leaves before touching the surfels
 
   // surfels of this thread: tile * kPoseTile + r * kPoseThreads + threadIdx.x (coalesced per r)
@@ -293,6 +298,21 @@ __global__ __launch_bounds__(kPoseThreads) BSLAM_POSE_WAVES_ATTR void pose_accum
     if (++stashed == kPoseStashGroup) { flush_rows(stashed); stashed = 0; stash_buf ^= 1; }
   }
   if (stashed) flush_rows(stashed);
+}
+
+// bslam_debug_wave_column_sums: wave_column_sums_lds on given values -- one wave, lane l holds in[l][0 .. 32), out[c] = the total
+// the lane that owns column c ends up with (columns nobody owns in this configuration stay as the caller set them).
+template <int kLive, int kCols>
+__global__ __launch_bounds__(64) void wave_column_sums_probe_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[kCols * 64];
+  float v[kRow];
+#pragma unroll
+  for (int i = 0; i < kRow; ++i) v[i] = in[threadIdx.x * kRow + i];
+  int col;
+  bool writer;
+  wave_column_sums_owner<kLive, kCols>(&col, &writer);
+  const float total = wave_column_sums_lds<kLive, kCols>(v, tile);
+  if (writer) out[col] = total;
 }
 
 // Sums the partial rows [k][row][32] of one keyframe in a fixed order, in two stages so that the

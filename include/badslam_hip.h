@@ -391,6 +391,12 @@ int bslam_debug_pose_residuals(
  * (tl .. br = the 2x2 texel footprint in [0, 1], tx, ty = fractional offsets of the sample).  tests/test_gpu_jacobians.py holds
  * these to the values of the reference's symbolic derivation (applications/badslam/scripts/jacobians_derivation.py). */
 int bslam_debug_jacobians(bslam_context* ctx, void* stream, int kind, int count, const float* in, float* out);
+/* Test probe of the wave reduction every per-keyframe sum goes through (wave_column_sums_lds, csrc/device_math.hpp): one wave,
+ * lane l holds in[32 l .. 32 l + 32) (HOST, 64 x 32 floats); out[c] (HOST, 32 floats, in / out) receives the total of column c
+ * over the 64 lanes from the lane that owns the column -- 0 for an owned column >= live_columns; columns no lane owns in the
+ * configuration keep the value they had.  (live_columns, columns_per_round) must be one of the kernels' configurations:
+ * (27 | 28, 4 | 8), (6, 4), (12, 4). */
+int bslam_debug_wave_column_sums(bslam_context* ctx, void* stream, int live_columns, int columns_per_round, const float* in, float* out);
 
 /* ------------------------------------------------------------------------- */
 /* Surfel lifecycle                                          */
