@@ -728,13 +728,10 @@ __device__ __forceinline__ void color_intrinsics_jacobian(float gx, float gy, fl
 #define BSLAM_HOIST_DEPTH_CAM_CENTRE(c) do { BSLAM_TO_VGPR((c).cx); BSLAM_TO_VGPR((c).cy); } while (0)   // kernels that never sample the colour image
 
 // ---------------------------------------------------------------------------------------------
-// XCD-aware work schedule.  Surfels are handled in granules of 256 consecutive columns.  The
-// host sorts the granules along a Morton curve of their centroids (`order`), and the sorted
-// sequence is cut into 8 contiguous ranges, one per XCD: workgroups are dealt round-robin over the
-// 8 XCDs (observed dispatch behaviour, used for speed only), so block b with b % 8 == x takes its
-// work from range x.  Each XCD then projects a compact part of the scene and touches only the
-// matching part of every keyframe image, instead of every XCD pulling every image through its own L2.
-// Any permutation is correct; a stale one only costs locality.
+// Work schedule.  Surfels are handled in granules of 256 consecutive columns, in the order of a Morton curve (per surfel for
+// long keyframe lists, per granule for short ones: badslam_hip.hip make_schedule), so that a workgroup's surfels are a compact
+// blob; workgroups are dealt round-robin over the 8 XCDs (observed dispatch behaviour, used for speed only) and take the work
+// slots in that order (slot_of_block).  Any permutation is correct; a stale one only costs locality.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGranule = 256;
 
@@ -746,12 +743,15 @@ struct Schedule {
   const float4* bounds;    // per-granule bounding boxes of the sorted copy (block-level frustum culling), or nullptr: no culling
 };
 
-// Work slot of block index b (of a 1-D launch of 8 * slots_per_xcd blocks), or false.
+// Work slot of block index b (of a 1-D launch of 8 * slots_per_xcd blocks), or false.  Block b takes slot b: workgroups are
+// dealt round-robin over the 8 XCDs, so consecutive slots -- neighbours in the Morton order -- go to different XCDs and every
+// XCD gets an even share of every part of the scene.  (Rounds 1 - 3 gave each XCD one CONTIGUOUS eighth of the order, for the
+// sake of its L2; the work of those eighths differs -- parts of the scene are seen by more keyframes than others, a short list of
+// keyframes sees one or two of them only -- and a launch lasted as long as the busiest XCD: dense K = 300 photometric pose
+// kernel 12.5 -> 10.2 ms, pcg_step1_kernel 13.8 -> 11.3 ms, survey-range stack 3.9 -> 2.75 ms per launch, same box.)
 __device__ __forceinline__ bool slot_of_block(const Schedule& sc, uint32_t b, uint32_t* slot) {
-  const uint32_t x = b & 7u, i = b >> 3;
-  const uint32_t s = x * sc.slots_per_xcd + i;
-  if (i >= sc.slots_per_xcd || s >= sc.slots) return false;
-  *slot = s;
+  if ((b >> 3) >= sc.slots_per_xcd || b >= sc.slots) return false;
+  *slot = b;
   return true;
 }
 
