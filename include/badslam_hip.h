@@ -168,9 +168,10 @@ int bslam_set_texture_mode(bslam_context* ctx, int mode);
 int bslam_set_keyframe_cache(bslam_context* ctx, int enable);
 int bslam_invalidate_keyframe_cache(bslam_context* ctx);
 
-/* XCD-aware scheduling (default on): surfels are visited along a Morton curve, one contiguous range
- * per XCD, so that every XCD's L2 only sees the part of each keyframe image its part of the scene
- * projects to.  Calls with at least 4 keyframes order the individual surfels by the Morton code of
+/* Work order of the surfel kernels (default on): surfels are visited along a Morton curve, the work
+ * slots of that order dealt round-robin over the XCDs (every XCD gets an even share of every part of
+ * the scene; up to round 3 each XCD took one contiguous eighth, and a launch lasted as long as the
+ * busiest eighth).  Calls with at least 4 keyframes order the individual surfels by the Morton code of
  * their positions (device radix sort, cached per surfel buffer) and read a sorted copy of the surfel
  * rows, so that a wave's 64 surfels project onto a few cache lines in every keyframe; shorter
  * keyframe lists (the per-keyframe entry points) order 256-column granules by their centroids.
